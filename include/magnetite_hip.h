@@ -1,0 +1,195 @@
+/*
+ * magnetite_hip.h -- C ABI of the MI355X-native Magnetite solver hot path.
+ *
+ * This is the boundary a Rust `extern "C"` shim inside Magnetite's
+ * `solver::run` binds (INTEGRATION.md shows the shim).  Every entry point
+ * cites the reference interface it replaces (file:line into
+ * kyle-tennison/Magnetite @ 2024_08_07).  Plain pointers and sizes only: no
+ * C++ types, no exceptions, no torch types cross this boundary.
+ *
+ * Data model across the boundary (Rust `Vec<Node>` / `Option<f64>` are not
+ * FFI-safe, so the shim flattens them -- datatypes.rs:1-29):
+ *   xy[2N]       f64  node.vertex.{x,y}, interleaved              datatypes.rs:1-5
+ *   conn[3E]     i32  element.nodes[0..3]                         datatypes.rs:17-18
+ *   u_known[2N]  u8   1: node.ux/uy is Some (displacement prescribed, force unknown)
+ *                     0: node.fx/fy is Some (force prescribed, displacement unknown)
+ *   u_in[2N]     f64  prescribed displacement, read where u_known==1
+ *   f_in[2N]     f64  prescribed force,        read where u_known==0
+ *   DOF index    2*node + {0:x, 1:y}                              solver.rs:306-307,346-351
+ * Every DOF has exactly one of (u,f) known -- the mesher guarantees it
+ * (mesher.rs:615-624,881-900); the reference panics otherwise (solver.rs:431).
+ * The shim checks it while flattening and reports MAG_ERR_BC_MISMATCH.
+ *
+ * Threading: one in-flight call per mag_ctx; calls block until the result is
+ * complete; distinct contexts may be used from distinct threads.
+ * Ownership: the caller owns every buffer it passes; the library keeps no
+ * pointer after a call returns (device-resident inputs passed with
+ * MAG_MEM_DEVICE are copied into context-owned buffers by mag_upload).
+ * Errors: int status (0 == MAG_OK) + mag_last_error(); never aborts/throws.
+ * The shim maps nonzero to MagnetiteError::Solver(msg) (error.rs:3-22).
+ */
+#ifndef MAGNETITE_HIP_H
+#define MAGNETITE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAG_ABI_VERSION 1
+
+/* solver.rs:17-19 */
+#define MAG_DOF 2
+#define MAG_MAX_CG_ITER 10000000LL
+#define MAG_TARGET_CG_COST 1e-4
+
+typedef struct mag_ctx mag_ctx;
+
+enum mag_status {
+    MAG_OK = 0,
+    MAG_ERR_BAD_ARGS = 1,
+    MAG_ERR_BC_MISMATCH = 2,   /* no unknown displacement / inconsistent BC set (solver.rs:431 panics) */
+    MAG_ERR_NOT_CONVERGED = 3, /* CG hit max_iter or broke down (solver.rs:160-174 -> Err)      */
+    MAG_ERR_HIP = 4,
+    MAG_ERR_RCCL = 5,
+    MAG_ERR_TOO_LARGE = 6,     /* an index would not fit int32                                   */
+    MAG_ERR_STATE = 7          /* call order: no problem uploaded / not run yet                   */
+};
+
+/* CG stop rule.  argmin 0.10 reports cost = f(r.r) and the reference stops on the
+ * ABSOLUTE threshold 1e-4 (solver.rs:153-154); whether f is sqrt or identity
+ * cannot be verified offline, so both exist; default = the tighter. */
+enum mag_stop {
+    MAG_STOP_RNORM = 0,    /* sqrt(r.r) <= tol            (reference-compatible default) */
+    MAG_STOP_RNORM_SQ = 1, /* r.r       <= tol                                            */
+    MAG_STOP_REL = 2       /* sqrt(r.r) <= tol*sqrt(b.b)  (BASELINE config 3: "CG to 1e-8") */
+};
+
+enum mag_operator {
+    MAG_OP_MATRIX_FREE = 0, /* element-loop operator, K never read in the CG loop */
+    MAG_OP_CSR = 1          /* reference-faithful: K_ff in CSR, solver.rs:31-36     */
+};
+
+enum mag_memory { MAG_MEM_HOST = 0, MAG_MEM_DEVICE = 1 };
+
+typedef struct mag_options {
+    int32_t device;       /* HIP device ordinal                                            */
+    int32_t stop_mode;    /* enum mag_stop, default MAG_STOP_RNORM                         */
+    double tol;           /* default MAG_TARGET_CG_COST (solver.rs:19)                     */
+    int64_t max_iter;     /* default MAG_MAX_CG_ITER   (solver.rs:18)                      */
+    int32_t cg_operator;  /* enum mag_operator, default MAG_OP_MATRIX_FREE                 */
+    int32_t assemble_csr; /* 1 (default): build K in CSR as the reference does and take
+                             the RHS and reactions from its rows; 0: matrix-free everywhere */
+    int32_t check_every;  /* CG iterations per host convergence poll (default 64, even)    */
+    int32_t use_graph;    /* 1 (default): replay the CG iteration block as a hipGraph      */
+    int32_t tile_nodes;   /* owned nodes per workgroup tile: 256 | 512 (default) | 1024    */
+    int32_t history_len;  /* keep the cost of the first history_len iterations (tests)     */
+    int32_t verbose;      /* 1: print the reference's "info:" phase lines to stdout        */
+    int32_t reserved[5];
+} mag_options;
+
+/* Borrowed view of the caller's flattened Vec<Node>/Vec<Element>/ModelMetadata
+ * (solver.rs:543-547 arguments). */
+typedef struct mag_problem {
+    int64_t num_nodes;
+    int64_t num_elements;
+    const double *xy;       /* 2N */
+    const int32_t *conn;    /* 3E */
+    const uint8_t *u_known; /* 2N */
+    const double *u_in;     /* 2N */
+    const double *f_in;     /* 2N */
+    double youngs_modulus;  /* ModelMetadata, datatypes.rs:22-29; solver.rs:559-561 */
+    double poisson_ratio;
+    double part_thickness;
+    int32_t memory; /* enum mag_memory: where the five arrays live */
+    int32_t reserved;
+} mag_problem;
+
+/* Caller-allocated outputs: every node.ux,uy,fx,fy and element.stress becomes
+ * Some(..) (solver.rs:476-482,532-533).  NULL members are skipped. */
+typedef struct mag_result {
+    double *u_out;      /* 2N */
+    double *f_out;      /* 2N */
+    double *stress_out; /* E  */
+    int32_t memory;     /* enum mag_memory */
+    int32_t reserved;
+} mag_result;
+
+typedef struct mag_stats {
+    int64_t iterations; /* "finished conjugate gradient approximation in {} iterations", solver.rs:101-104 */
+    double final_cost;  /* cost of the returned iterate under stop_mode */
+    double rhs_norm;    /* sqrt(b.b) */
+    int32_t converged;
+    int32_t breakdown;  /* non-finite r.r */
+    int64_t n_free;     /* unknown displacements */
+    int64_t nnz;        /* scalar nnz of K (0 if not assembled) */
+    int64_t num_tiles;
+    int64_t ell_entries; /* (node,incident element) slots incl. padding */
+    /* per-phase device time, HIP events on the context's stream, milliseconds */
+    double ms_order;     /* Hilbert ordering + incidence + tile tables (symbolic, matrix-free op) */
+    double ms_csr_symbolic;
+    double ms_element;   /* K_e build, solver.rs:548-567 */
+    double ms_assemble;  /* numeric gather into CSR, solver.rs:290-331 */
+    double ms_bc;        /* RHS / partition, solver.rs:365-404,427-432 */
+    double ms_cg;        /* solver.rs:435-441 timed region minus the dense->CSR scan */
+    double ms_post;      /* scatter-back, reactions, stress */
+    double ms_total;
+} mag_stats;
+
+/* ---- lifecycle ------------------------------------------------------- */
+int mag_version(void);
+void mag_default_options(mag_options *opt);
+/* NULL opt => defaults.  Returns NULL only if the context itself cannot be allocated. */
+mag_ctx *mag_create(const mag_options *opt);
+void mag_destroy(mag_ctx *ctx);
+const char *mag_last_error(const mag_ctx *ctx);
+
+/* ---- the drop-in entry: replaces solver::run, solver.rs:543-586 ------ */
+/* upload -> run -> download in one blocking call. */
+int mag_solve(mag_ctx *ctx, const mag_problem *problem, mag_result *result);
+
+/* The same, split so a caller (bench.py) can keep inputs resident in HBM:
+ *   mag_upload   copies the problem into context-owned device buffers
+ *   mag_run      K_e build, assembly, BC elimination, CG, reactions, stress (solver.rs:548-583)
+ *   mag_download copies u/f/stress out */
+int mag_upload(mag_ctx *ctx, const mag_problem *problem);
+int mag_run(mag_ctx *ctx);
+int mag_download(mag_ctx *ctx, mag_result *result);
+int mag_get_stats(const mag_ctx *ctx, mag_stats *stats);
+/* cost of CG iterations 1..n (n <= options.history_len, <= iterations) */
+int mag_get_history(mag_ctx *ctx, double *history, int64_t n);
+
+/* ---- pieces of the path, exposed for parity tests -------------------- */
+/* solver.rs:187-193 compute_element_area (pub; the mesher imports it, mesher.rs:9,523). Host-side. */
+double mag_compute_element_area(const double *xy, const int32_t *tri);
+/* solver.rs:263-278 for every element of the uploaded problem: ke_out[36E] host, row-major 6x6. */
+int mag_element_stiffness(mag_ctx *ctx, double *ke_out);
+/* solver.rs:290-331: K (2N x 2N) in CSR, ascending columns, structural pattern.
+ * Call once with all outputs NULL to get nnz, then with host buffers rowptr[2N+1], col[nnz], val[nnz]. */
+int mag_assemble_csr(mag_ctx *ctx, int64_t *nnz, int32_t *rowptr, int32_t *col, double *val);
+/* solver.rs:365-404,427-432,123-137: K_ff with exact zeros dropped + b, compact unknown numbering.
+ * Same two-call pattern: rowptr[n_free+1], col[nnz_ff], val[nnz_ff], b[n_free]. */
+int mag_reduce_system(mag_ctx *ctx, int64_t *n_free, int64_t *nnz_ff, int32_t *rowptr, int32_t *col,
+                      double *val, double *b);
+/* y = K x with the matrix-free element-loop operator on the uploaded mesh
+ * (x, y: host, 2N, caller's DOF numbering).  masked != 0 applies M K M with M
+ * zeroing prescribed-displacement DOFs (that is K_ff embedded in full length). */
+int mag_apply_operator(mag_ctx *ctx, const double *x, double *y, int32_t masked);
+/* Bench helper: `reps` back-to-back launches of the operator kernel on the context's
+ * stream between two HIP events; *ms_per_launch = elapsed / reps. */
+int mag_time_operator(mag_ctx *ctx, int32_t reps, double *ms_per_launch);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ------------------- */
+#define MAG_UNIQUE_ID_BYTES 128
+/* rank 0 calls this and broadcasts the bytes out of band (bench.py: torch.distributed) */
+int mag_comm_get_unique_id(void *id_out);
+int mag_comm_init_rccl(mag_ctx *ctx, const void *unique_id, int32_t nranks, int32_t rank);
+/* test transport: sum-all-reduce of a host buffer supplied by the caller (gloo in tests/) */
+typedef int (*mag_allreduce_fn)(void *user, double *host_buf, int64_t count);
+int mag_comm_init_callback(mag_ctx *ctx, int32_t nranks, int32_t rank, mag_allreduce_fn fn, void *user);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAGNETITE_HIP_H */

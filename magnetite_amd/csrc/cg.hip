@@ -1,0 +1,415 @@
+// Matrix-free element-loop operator and the fused CG iteration for gfx950.
+//
+// Replaces the per-iteration work of solver.rs:31-36 (CSR SpMV) and of argmin's
+// ConjugateGradient::next_iter (solver.rs:142-157; recurrences in SURVEY 3.3):
+//     q = A p; alpha = rtr/(p.q); x += alpha p; r += alpha q;
+//     rtr' = r.r; beta = rtr'/rtr; p = -r + beta p; cost = f(rtr')
+// with r = A x - b (argmin's sign).  A = M K M acts on full-length vectors
+// (M zeroes prescribed-displacement DOFs), i.e. K_ff embedded in 2N.
+//
+// Layout: nodes are in Hilbert order; workgroup tile t owns nodes
+// [t*B, (t+1)*B).  One thread owns one node (both DOFs, double2).  The tile's
+// coordinates and p are staged in LDS; every incident element of a node is
+// visited through the tile's ELL table (slot-major => coalesced int2 reads),
+// and the thread accumulates only ITS corner's force  f_a = t*A * B_a^T D B u_e
+// -- owner-computes, so there is no scatter, no atomic and no colouring pass,
+// and the summation order per node is fixed (ascending element index).
+// Corners owned by another tile are fetched from global memory (L2) and their
+// p is recomputed from r and p_prev, which are stable during the launch.
+//
+// Two launches per CG iteration; the two dot products are reduced in a fixed
+// order from <= kMaxGrid per-workgroup partials by every workgroup of the
+// NEXT launch (the kernel boundary is the grid-wide sync), so results are
+// bitwise reproducible run to run.
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace magk {
+
+int cg_grid(int32_t T) { return T < kMaxGrid ? (T < 1 ? 1 : T) : kMaxGrid; }
+
+// ------------------------------------------------------------ reductions ---
+template <int B>
+__device__ inline double block_sum(double v, double *s_red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < B / 64; ++i) t += s_red[i];
+    return t; // identical in every thread
+}
+
+template <int B>
+__device__ inline double sum_partials(const double *part, int n, double *s_red)
+{
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += B) v += part[i];
+    return block_sum<B>(v, s_red);
+}
+
+// 1/a to full fp64 precision from the hardware seed (two Newton steps); the
+// IEEE division sequence is ~3x the instructions and this is per (node, element).
+__device__ inline double fast_rcp(double a)
+{
+    double y = __builtin_amdgcn_rcp(a);
+    double e = fma(-a, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-a, y, 1.0);
+    y = fma(y, e, y);
+    return y;
+}
+
+// Force on corner a of the CST (a, b, c) for nodal values pa, pb, pc:
+//   2A eps = (sum beta_i u_i, sum gamma_i v_i, sum gamma_i u_i + beta_i v_i)     solver.rs:213-225
+//   sigma  = D eps                                                                solver.rs:241-247
+//   f_a    = t A B_a^T sigma = c0/(2A) * [beta_a sx' + gamma_a t', gamma_a sy' + beta_a t']
+// with c0 = E t / (2 (1 - nu^2)) and primes denoting the unscaled (2A eps) quantities.
+// 2A is taken from coordinate differences (signed, like solver.rs:192).
+__device__ inline void corner_force(const double2 ca, const double2 pa, const double2 cb, const double2 pb,
+                                    const double2 cc, const double2 pc, double c0, double nu, double h, double &fx,
+                                    double &fy)
+{
+    const double ba = cb.y - cc.y, bb = cc.y - ca.y, bc = ca.y - cb.y;
+    const double ga = cc.x - cb.x, gb = ca.x - cc.x, gc = cb.x - ca.x;
+    const double twoA = gc * bb - gb * bc;
+    const double ex = ba * pa.x + bb * pb.x + bc * pc.x;
+    const double ey = ga * pa.y + gb * pb.y + gc * pc.y;
+    const double g = ga * pa.x + ba * pa.y + gb * pb.x + bb * pb.y + gc * pc.x + bc * pc.y;
+    const double w = c0 * fast_rcp(twoA);
+    const double sx = ex + nu * ey, sy = nu * ex + ey, tq = h * g;
+    fx += w * (ba * sx + ga * tq);
+    fy += w * (ga * sy + ba * tq);
+}
+
+// ------------------------------------------------------ operator kernel ---
+template <int B, bool CG>
+__global__ void __launch_bounds__(B) k_operator(const OpParams P)
+{
+    __shared__ double2 s_xy[B];
+    __shared__ double2 s_p[B];
+    __shared__ double s_red[B / 64];
+
+    double beta = 0.0;
+    if (CG) {
+        CgState *st = P.st;
+        const long long k = st->iterA;
+        const int was_done = st->done;
+        const double rr = sum_partials<B>(P.partRR, P.nPart, s_red);
+        if (was_done) return;
+        const double cost = st->stop_mode == 1 ? fabs(rr) : sqrt(rr);
+        const bool finished = (k >= 1) && (cost <= st->target);
+        const bool broke = !(fabs(rr) <= 1.79769313486231570e308); // NaN or inf
+        const bool maxed = k >= st->max_iter;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (k >= 1 && k - 1 < P.hist_len) P.hist[k - 1] = cost;
+            if (finished || broke || maxed) {
+                st->iterations = k;
+                st->final_cost = cost;
+                st->converged = finished ? 1 : 0;
+                st->breakdown = broke ? 1 : 0;
+                st->done = 1;
+            } else {
+                st->rr_hist[k & 1] = rr;
+                st->iterB = k;
+            }
+        }
+        if (finished || broke || maxed) return;
+        const double rr_prev = (k == 0) ? rr : st->rr_hist[(k + 1) & 1];
+        beta = rr / rr_prev;
+    }
+
+    const double c0 = P.c0, nu = P.nu, h = P.h;
+    double acc = 0.0;
+    for (int32_t t = blockIdx.x; t < P.T; t += gridDim.x) {
+        const int64_t base = (int64_t)t * B;
+        const int64_t node = base + threadIdx.x;
+        const bool valid = node < P.N;
+        double2 ca = make_double2(0.0, 0.0), pa = make_double2(0.0, 0.0);
+        uint8_t m = 3;
+        if (valid) {
+            ca = P.xyP[node];
+            m = P.maskP[node];
+            if (CG) {
+                const double2 r2 = P.r[node], pp = P.pprev[node];
+                pa.x = -r2.x + beta * pp.x;
+                pa.y = -r2.y + beta * pp.y;
+                P.pnew[node] = pa;
+            } else {
+                pa = P.v[node];
+                if (P.masked) {
+                    if (m & 1) pa.x = 0.0;
+                    if (m & 2) pa.y = 0.0;
+                }
+            }
+        }
+        __syncthreads(); // previous tile's readers are done with the LDS images
+        s_xy[threadIdx.x] = ca;
+        s_p[threadIdx.x] = pa;
+        __syncthreads();
+
+        const int32_t deg = P.tile_deg[t];
+        const int2 *ell = P.ell + P.tile_off[t] + threadIdx.x;
+        double fx = 0.0, fy = 0.0;
+        for (int32_t k = 0; k < deg; ++k) {
+            const int2 bc = ell[(int64_t)k * B];
+            if (bc.x < 0) continue;
+            double2 cb, pb, cc, pc;
+            const uint32_t lb = (uint32_t)(bc.x - (int32_t)base), lc = (uint32_t)(bc.y - (int32_t)base);
+            if (lb < (uint32_t)B) {
+                cb = s_xy[lb];
+                pb = s_p[lb];
+            } else {
+                cb = P.xyP[bc.x];
+                if (CG) {
+                    const double2 r2 = P.r[bc.x], pp = P.pprev[bc.x];
+                    pb.x = -r2.x + beta * pp.x;
+                    pb.y = -r2.y + beta * pp.y;
+                } else {
+                    pb = P.v[bc.x];
+                    if (P.masked) {
+                        const uint8_t mb = P.maskP[bc.x];
+                        if (mb & 1) pb.x = 0.0;
+                        if (mb & 2) pb.y = 0.0;
+                    }
+                }
+            }
+            if (lc < (uint32_t)B) {
+                cc = s_xy[lc];
+                pc = s_p[lc];
+            } else {
+                cc = P.xyP[bc.y];
+                if (CG) {
+                    const double2 r2 = P.r[bc.y], pp = P.pprev[bc.y];
+                    pc.x = -r2.x + beta * pp.x;
+                    pc.y = -r2.y + beta * pp.y;
+                } else {
+                    pc = P.v[bc.y];
+                    if (P.masked) {
+                        const uint8_t mc = P.maskP[bc.y];
+                        if (mc & 1) pc.x = 0.0;
+                        if (mc & 2) pc.y = 0.0;
+                    }
+                }
+            }
+            corner_force(ca, pa, cb, pb, cc, pc, c0, nu, h, fx, fy);
+        }
+        if (valid) {
+            if (CG || P.masked) {
+                if (m & 1) fx = 0.0;
+                if (m & 2) fy = 0.0;
+            }
+            if (CG) {
+                P.q[node] = make_double2(fx, fy);
+                acc += pa.x * fx + pa.y * fy;
+            } else {
+                P.y[node] = make_double2(fx, fy);
+            }
+        }
+    }
+    if (CG) {
+        const double tot = block_sum<B>(acc, s_red);
+        if (threadIdx.x == 0) P.partPQ[blockIdx.x] = tot;
+    }
+}
+
+void op_launch(const OpParams &P, int32_t B, bool cg_mode, hipStream_t s)
+{
+    const int grid = cg_grid(P.T);
+#define MAG_OP(BB)                                                     \
+    if (cg_mode)                                                       \
+        k_operator<BB, true><<<grid, BB, 0, s>>>(P);                   \
+    else                                                               \
+        k_operator<BB, false><<<grid, BB, 0, s>>>(P);
+    if (B == 256) {
+        MAG_OP(256)
+    } else if (B == 1024) {
+        MAG_OP(1024)
+    } else {
+        MAG_OP(512)
+    }
+#undef MAG_OP
+}
+
+// -------------------------------------------------------- update kernel ---
+// alpha = rtr/(p.q); x += alpha p; r += alpha q; partial r.r   (argmin next_iter)
+template <int B>
+__global__ void __launch_bounds__(B) k_update(const UpdParams P)
+{
+    __shared__ double s_red[B / 64];
+    CgState *st = P.st;
+    const int done = st->done;
+    const long long k = st->iterB;
+    const double pq = sum_partials<B>(P.partPQ, P.nPart, s_red);
+    if (done) return;
+    const double alpha = st->rr_hist[k & 1] / pq;
+    double acc = 0.0;
+    for (int32_t t = blockIdx.x; t < P.T; t += gridDim.x) {
+        const int64_t node = (int64_t)t * B + threadIdx.x;
+        if (node < P.N) {
+            const double2 p = P.p[node], q = P.q[node];
+            double2 x = P.x[node], r = P.r[node];
+            x.x += alpha * p.x;
+            x.y += alpha * p.y;
+            r.x += alpha * q.x;
+            r.y += alpha * q.y;
+            P.x[node] = x;
+            P.r[node] = r;
+            acc += r.x * r.x + r.y * r.y;
+        }
+    }
+    const double tot = block_sum<B>(acc, s_red);
+    if (threadIdx.x == 0) {
+        P.partRR[blockIdx.x] = tot;
+        if (blockIdx.x == 0) {
+            st->iterA = k + 1;
+            st->alpha_last = alpha;
+        }
+    }
+}
+
+void upd_launch(const UpdParams &P, int32_t B, hipStream_t s)
+{
+    const int grid = cg_grid(P.T);
+    if (B == 256)
+        k_update<256><<<grid, 256, 0, s>>>(P);
+    else if (B == 1024)
+        k_update<1024><<<grid, 1024, 0, s>>>(P);
+    else
+        k_update<512><<<grid, 512, 0, s>>>(P);
+}
+
+// ------------------------------------------------------------ init/setup ---
+// argmin init: r0 = -(b - A x0) with x0 = 0 (solver.rs:143) => r0 = -b; p0 = -r0 comes out of the
+// first operator launch (beta = 1, p_prev = 0).
+template <int B>
+__global__ void __launch_bounds__(B) k_cg_init(const double2 *bP, double2 *r, int64_t N, int32_t T, double *partRR)
+{
+    __shared__ double s_red[B / 64];
+    double acc = 0.0;
+    for (int32_t t = blockIdx.x; t < T; t += gridDim.x) {
+        const int64_t node = (int64_t)t * B + threadIdx.x;
+        if (node < N) {
+            const double2 b = bP[node];
+            const double2 v = make_double2(-b.x, -b.y);
+            r[node] = v;
+            acc += v.x * v.x + v.y * v.y;
+        }
+    }
+    const double tot = block_sum<B>(acc, s_red);
+    if (threadIdx.x == 0) partRR[blockIdx.x] = tot;
+}
+
+void cg_init(const double2 *bP, double2 *r, int64_t N, int32_t B, int32_t T, double *partRR, hipStream_t s)
+{
+    const int grid = cg_grid(T);
+    if (B == 256)
+        k_cg_init<256><<<grid, 256, 0, s>>>(bP, r, N, T, partRR);
+    else if (B == 1024)
+        k_cg_init<1024><<<grid, 1024, 0, s>>>(bP, r, N, T, partRR);
+    else
+        k_cg_init<512><<<grid, 512, 0, s>>>(bP, r, N, T, partRR);
+}
+
+__global__ void __launch_bounds__(256) k_cg_setup(const double *partRR, int nPart, int stop_mode, double tol,
+                                                  long long max_iter, CgState *st)
+{
+    __shared__ double s_red[4];
+    const double bb = sum_partials<256>(partRR, nPart, s_red);
+    if (threadIdx.x == 0) {
+        st->rr_hist[0] = bb;
+        st->rr_hist[1] = bb;
+        st->bb = bb;
+        st->tol = tol;
+        st->target = stop_mode == 2 ? tol * sqrt(bb) : tol;
+        st->stop_mode = stop_mode;
+        st->final_cost = stop_mode == 1 ? bb : sqrt(bb);
+        st->alpha_last = 0.0;
+        st->iterA = 0;
+        st->iterB = 0;
+        st->iterations = 0;
+        st->max_iter = max_iter;
+        st->breakdown = 0;
+        // b == 0: the first alpha would be 0/0; return x = 0 (documented deviation, see oracle orc_cg)
+        st->done = (bb == 0.0) ? 1 : 0;
+        st->converged = (bb == 0.0) ? 1 : 0;
+        if (bb == 0.0) st->final_cost = 0.0;
+    }
+}
+
+void cg_setup(const double *partRR, int32_t nPart, int stop_mode, double tol, long long max_iter, CgState *st,
+              hipStream_t s)
+{
+    k_cg_setup<<<1, 256, 0, s>>>(partRR, nPart, stop_mode, tol, max_iter, st);
+}
+
+// --------------------------------------------------- numbering helpers ---
+static inline int blocks_for(int64_t n, int threads)
+{
+    int64_t b = (n + threads - 1) / threads;
+    return (int)(b < 1 ? 1 : b);
+}
+
+__global__ void __launch_bounds__(256) k_to_hilbert(const double *v, const int32_t *iperm, const uint8_t *u_known,
+                                                    int32_t masked, int64_t N, double *vP)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= 2 * N) return;
+    vP[2 * (int64_t)iperm[r >> 1] + (r & 1)] = (masked && u_known[r]) ? 0.0 : v[r];
+}
+
+void to_hilbert(const double *v, const int32_t *iperm, const uint8_t *u_known, int32_t masked, int64_t N, double *vP,
+                hipStream_t s)
+{
+    k_to_hilbert<<<blocks_for(2 * N, 256), 256, 0, s>>>(v, iperm, u_known, masked, N, vP);
+}
+
+__global__ void __launch_bounds__(256) k_from_hilbert(const double *yP, const int32_t *iperm, int64_t N, double *y)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= 2 * N) return;
+    y[r] = yP[2 * (int64_t)iperm[r >> 1] + (r & 1)];
+}
+
+void from_hilbert(const double *yP, const int32_t *iperm, int64_t N, double *y, hipStream_t s)
+{
+    k_from_hilbert<<<blocks_for(2 * N, 256), 256, 0, s>>>(yP, iperm, N, y);
+}
+
+__global__ void __launch_bounds__(256) k_known_to_hilbert(const double *u_in, const uint8_t *u_known,
+                                                          const int32_t *iperm, int64_t N, double *uP)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= 2 * N) return;
+    uP[2 * (int64_t)iperm[r >> 1] + (r & 1)] = u_known[r] ? u_in[r] : 0.0;
+}
+
+void known_to_hilbert(const double *u_in, const uint8_t *u_known, const int32_t *iperm, int64_t N, double *uP,
+                      hipStream_t s)
+{
+    k_known_to_hilbert<<<blocks_for(2 * N, 256), 256, 0, s>>>(u_in, u_known, iperm, N, uP);
+}
+
+// b = f_known - K_fk u_known on free rows (solver.rs:427-432), matrix-free: yP = K * u_ext
+__global__ void __launch_bounds__(256) k_rhs_from_apply(const double *yP, const double *f_in, const uint8_t *u_known,
+                                                        const uint32_t *perm, int64_t N, double *bP)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; // Hilbert DOF index
+    if (r >= 2 * N) return;
+    const int64_t o = 2 * (int64_t)perm[r >> 1] + (r & 1);
+    bP[r] = u_known[o] ? 0.0 : (-yP[r] + f_in[o]);
+}
+
+void rhs_from_apply(const double *yP, const double *f_in, const uint8_t *u_known, const uint32_t *perm, int64_t N,
+                    double *bP, hipStream_t s)
+{
+    k_rhs_from_apply<<<blocks_for(2 * N, 256), 256, 0, s>>>(yP, f_in, u_known, perm, N, bP);
+}
+
+} // namespace magk

@@ -1,0 +1,266 @@
+// Reference-order fp64 arithmetic of the path, one kernel per reference
+// function.  Compiled with -ffp-contract=off: the Rust reference never fuses
+// a*b+c, and nalgebra's static matrix product sums ascending k starting from
+// the k=0 product (gemm -> gemv -> axcpy), so K_e, the assembled K, the RHS
+// and the stress scalar reproduce the reference's rounding, not just its
+// formulas.  None of these kernels is in the CG loop.
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace magk {
+
+static inline int blocks_for(int64_t n, int threads)
+{
+    int64_t b = (n + threads - 1) / threads;
+    return (int)(b < 1 ? 1 : b);
+}
+
+// C[m x n] = A[m x k] * B[k x n], row major, ascending-k sums from the first product
+template <int M, int K, int N>
+__device__ inline void matmul(const double *a, const double *b, double *c)
+{
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double s = a[i * K] * b[j];
+#pragma unroll
+            for (int l = 1; l < K; ++l) s = s + a[i * K + l] * b[l * N + j];
+            c[i * N + j] = s;
+        }
+}
+
+// solver.rs:187-193
+__device__ inline double signed_area(double x0, double y0, double x1, double y1, double x2, double y2)
+{
+    return 0.5 * (x0 * (y1 - y2) + x1 * (y2 - y0) + x2 * (y0 - y1));
+}
+
+// solver.rs:204-230
+__device__ inline void strain_displacement(double x0, double y0, double x1, double y1, double x2, double y2,
+                                           double area, double *B)
+{
+    const double b1 = y1 - y2, b2 = y2 - y0, b3 = y0 - y1;
+    const double g1 = x2 - x1, g2 = x0 - x2, g3 = x1 - x0;
+    const double m[18] = {b1, 0., b2, 0., b3, 0., 0., g1, 0., g2, 0., g3, g1, b1, g2, b2, g3, b3};
+    const double d = 2.0 * area;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) B[i] = m[i] / d;
+}
+
+// solver.rs:240-250
+__device__ inline void stress_strain(double nu, double youngs, double *D)
+{
+    const double m[9] = {1.0, nu, 0.0, nu, 1.0, 0.0, 0.0, 0.0, (1.0 - nu) / 2.0};
+    const double s = youngs / (1.0 - nu * nu);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) D[i] = m[i] * s;
+}
+
+// solver.rs:263-278 + the loop of solver.rs:548-567: one thread per element.
+__global__ void __launch_bounds__(256) k_element_stiffness(const double2 *xy, const int32_t *conn, int64_t E,
+                                                           double nu, double youngs, double thick, double *ke)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const double2 v0 = xy[conn[3 * e]], v1 = xy[conn[3 * e + 1]], v2 = xy[conn[3 * e + 2]];
+    const double area = signed_area(v0.x, v0.y, v1.x, v1.y, v2.x, v2.y);
+    double D[9], B[18], Bt[18], BtD[18], K[36];
+    stress_strain(nu, youngs, D);
+    strain_displacement(v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, area, B);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) Bt[j * 3 + i] = B[i * 6 + j];
+    matmul<6, 3, 3>(Bt, D, BtD);
+    matmul<6, 3, 6>(BtD, B, K);
+    double *out = ke + 36 * e;
+#pragma unroll
+    for (int i = 0; i < 36; ++i) out[i] = K[i] * area * thick;
+}
+
+void element_stiffness(const double *xy, const int32_t *conn, int64_t E, double nu, double youngs, double thick,
+                       double *ke, hipStream_t s)
+{
+    k_element_stiffness<<<blocks_for(E, 256), 256, 0, s>>>((const double2 *)xy, conn, E, nu, youngs, thick, ke);
+}
+
+// solver.rs:290-331 without the dense matrix and without atomics: the sorted
+// (row node, col node) pair list groups every '+=' that lands on one 2x2
+// block; inside a group the stable sort kept ascending element order, which
+// is the reference's summation order (0.0 + first contribution is exact).
+__global__ void __launch_bounds__(256) k_assemble_gather(const uint64_t *keys, const uint32_t *vals,
+                                                         const int32_t *seg_start, int64_t nb, const int32_t *bptr,
+                                                         const double *ke, double *kval)
+{
+    const int64_t blk = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (blk >= nb) return;
+    const int32_t s0 = seg_start[blk], s1 = seg_start[blk + 1];
+    const int32_t i = (int32_t)(keys[s0] >> 32);
+    double k00 = 0.0, k01 = 0.0, k10 = 0.0, k11 = 0.0;
+    for (int32_t k = s0; k < s1; ++k) {
+        const uint32_t v = vals[k];
+        const uint32_t e = v / 9u, ab = v - 9u * e;
+        const uint32_t a = ab / 3u, b = ab - 3u * a;
+        const double *src = ke + 36 * (int64_t)e + 12 * a + 2 * b; // K_e[2a][2b]
+        k00 += src[0];
+        k01 += src[1];
+        k10 += src[6];
+        k11 += src[7];
+    }
+    const int32_t p = bptr[i], cnt = bptr[i + 1] - p, kpos = (int32_t)blk - p;
+    double *r0 = kval + 4 * (int64_t)p + 2 * kpos;
+    double *r1 = kval + 4 * (int64_t)p + 2 * cnt + 2 * kpos;
+    r0[0] = k00;
+    r0[1] = k01;
+    r1[0] = k10;
+    r1[1] = k11;
+}
+
+void assemble_gather(const uint64_t *keys, const uint32_t *vals, const int32_t *seg_start, int64_t nb,
+                     const int32_t *bptr, const double *ke, double *kval, hipStream_t s)
+{
+    k_assemble_gather<<<blocks_for(nb, 256), 256, 0, s>>>(keys, vals, seg_start, nb, bptr, ke, kval);
+}
+
+// solver.rs:365-404 + 427-432 on the CSR rows: known[r,k] = -(K[r,col]*u[col]) summed ascending, + f.
+__device__ inline double rhs_row(const int32_t *bptr, const int32_t *bcol, const double *kval, const uint8_t *u_known,
+                                 const double *u_in, const double *f_in, int64_t r)
+{
+    const int64_t i = r >> 1;
+    const int a = (int)(r & 1);
+    const int32_t p = bptr[i], nb = bptr[i + 1] - p;
+    const double *row = kval + 4 * (int64_t)p + (int64_t)a * 2 * nb;
+    double s = 0.0;
+    for (int k = 0; k < nb; ++k) {
+        const int64_t j = bcol[p + k];
+        if (u_known[2 * j]) s += (row[2 * k] * u_in[2 * j]) * -1.0;
+        if (u_known[2 * j + 1]) s += (row[2 * k + 1] * u_in[2 * j + 1]) * -1.0;
+    }
+    return s + f_in[r];
+}
+
+__global__ void __launch_bounds__(256) k_rhs_from_csr(const int32_t *bptr, const int32_t *bcol, const double *kval,
+                                                      const uint8_t *u_known, const double *u_in, const double *f_in,
+                                                      const int32_t *iperm, int64_t N, double *bP)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= 2 * N) return;
+    const double v = u_known[r] ? 0.0 : rhs_row(bptr, bcol, kval, u_known, u_in, f_in, r);
+    bP[2 * (int64_t)iperm[r >> 1] + (r & 1)] = v;
+}
+
+void rhs_from_csr(const int32_t *bptr, const int32_t *bcol, const double *kval, const uint8_t *u_known,
+                  const double *u_in, const double *f_in, const int32_t *iperm, int64_t N, double *bP, hipStream_t s)
+{
+    k_rhs_from_csr<<<blocks_for(2 * N, 256), 256, 0, s>>>(bptr, bcol, kval, u_known, u_in, f_in, iperm, N, bP);
+}
+
+__global__ void __launch_bounds__(256) k_rhs_compact(const int32_t *bptr, const int32_t *bcol, const double *kval,
+                                                     const uint8_t *u_known, const double *u_in, const double *f_in,
+                                                     const int32_t *fidx, int64_t N, double *b)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= 2 * N || u_known[r]) return;
+    b[fidx[r]] = rhs_row(bptr, bcol, kval, u_known, u_in, f_in, r);
+}
+
+void rhs_compact(const int32_t *bptr, const int32_t *bcol, const double *kval, const uint8_t *u_known,
+                 const double *u_in, const double *f_in, const int32_t *fidx, int64_t N, double *b, hipStream_t s)
+{
+    k_rhs_compact<<<blocks_for(2 * N, 256), 256, 0, s>>>(bptr, bcol, kval, u_known, u_in, f_in, fidx, N, b);
+}
+
+// solver.rs:443-454
+__global__ void __launch_bounds__(256) k_scatter_back(const double2 *xP, const uint32_t *perm, const uint8_t *u_known,
+                                                      const double *u_in, int64_t N, double *u)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int64_t o = perm[i];
+    const double2 x = xP[i];
+    u[2 * o] = u_known[2 * o] ? u_in[2 * o] : x.x;
+    u[2 * o + 1] = u_known[2 * o + 1] ? u_in[2 * o + 1] : x.y;
+}
+
+void scatter_back(const double *xP, const uint32_t *perm, const uint8_t *u_known, const double *u_in, int64_t N,
+                  double *u, hipStream_t s)
+{
+    k_scatter_back<<<blocks_for(N, 256), 256, 0, s>>>((const double2 *)xP, perm, u_known, u_in, N, u);
+}
+
+// solver.rs:456-469: full row . u in ascending column order (structural zeros of the dense row add +-0)
+__global__ void __launch_bounds__(256) k_reactions_from_csr(const int32_t *bptr, const int32_t *bcol,
+                                                            const double *kval, const uint8_t *u_known,
+                                                            const double *u, const double *f_in, int64_t N, double *f)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= 2 * N) return;
+    if (!u_known[r]) {
+        f[r] = f_in[r];
+        return;
+    }
+    const int64_t i = r >> 1;
+    const int a = (int)(r & 1);
+    const int32_t p = bptr[i], nb = bptr[i + 1] - p;
+    const double *row = kval + 4 * (int64_t)p + (int64_t)a * 2 * nb;
+    double s = 0.0;
+    for (int k = 0; k < nb; ++k) {
+        const int64_t j = bcol[p + k];
+        s += row[2 * k] * u[2 * j];
+        s += row[2 * k + 1] * u[2 * j + 1];
+    }
+    f[r] = s;
+}
+
+void reactions_from_csr(const int32_t *bptr, const int32_t *bcol, const double *kval, const uint8_t *u_known,
+                        const double *u, const double *f_in, int64_t N, double *f, hipStream_t s)
+{
+    k_reactions_from_csr<<<blocks_for(2 * N, 256), 256, 0, s>>>(bptr, bcol, kval, u_known, u, f_in, N, f);
+}
+
+__global__ void __launch_bounds__(256) k_reactions_from_apply(const double *yP, const int32_t *iperm,
+                                                              const uint8_t *u_known, const double *f_in, int64_t N,
+                                                              double *f)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= 2 * N) return;
+    f[r] = u_known[r] ? yP[2 * (int64_t)iperm[r >> 1] + (r & 1)] : f_in[r];
+}
+
+void reactions_from_apply(const double *yP, const int32_t *iperm, const uint8_t *u_known, const double *f_in,
+                          int64_t N, double *f, hipStream_t s)
+{
+    k_reactions_from_apply<<<blocks_for(2 * N, 256), 256, 0, s>>>(yP, iperm, u_known, f_in, N, f);
+}
+
+// solver.rs:496-535: sigma = (D*B)*u_e; scalar = sqrt(sx^2+sy^2) * (sx+sy < 1.0 ? -1 : 1) -- quirk kept.
+__global__ void __launch_bounds__(256) k_element_stress(const double2 *xy, const int32_t *conn, const double2 *u,
+                                                        int64_t E, double nu, double youngs, double *stress)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int32_t n0 = conn[3 * e], n1 = conn[3 * e + 1], n2 = conn[3 * e + 2];
+    const double2 v0 = xy[n0], v1 = xy[n1], v2 = xy[n2];
+    const double2 u0 = u[n0], u1 = u[n1], u2 = u[n2];
+    const double ue[6] = {u0.x, u0.y, u1.x, u1.y, u2.x, u2.y};
+    double D[9], B[18], DB[18], sg[3];
+    stress_strain(nu, youngs, D);
+    strain_displacement(v0.x, v0.y, v1.x, v1.y, v2.x, v2.y, signed_area(v0.x, v0.y, v1.x, v1.y, v2.x, v2.y), B);
+    matmul<3, 3, 6>(D, B, DB);
+    matmul<3, 6, 1>(DB, ue, sg);
+    const double sign = (sg[0] + sg[1] < 1.0) ? -1.0 : 1.0;
+    stress[e] = sqrt(sg[0] * sg[0] + sg[1] * sg[1]) * sign;
+}
+
+void element_stress(const double *xy, const int32_t *conn, const double *u, int64_t E, double nu, double youngs,
+                    double *stress, hipStream_t s)
+{
+    k_element_stress<<<blocks_for(E, 256), 256, 0, s>>>((const double2 *)xy, conn, (const double2 *)u, E, nu, youngs,
+                                                        stress);
+}
+
+} // namespace magk

@@ -1,0 +1,159 @@
+// Internal: launch wrappers of the hand-written gfx950 kernels.
+//   symbolic.hip  integer kernels of the one-time symbolic phases
+//   exact.hip     reference-order fp64 arithmetic (compiled -ffp-contract=off)
+//   cg.hip        matrix-free element-loop operator + fused CG kernels
+#pragma once
+#include <cstdint>
+
+#include <hip/hip_runtime.h>
+
+namespace magk {
+
+constexpr int kMaxGrid = 1024;  // cap on workgroups of the CG kernels == number of dot partials
+constexpr int kHilbertBits = 16;
+
+// ------------------------------------------------------------ symbolic.hip
+// bbox[4] = {xmin, ymin, xmax, ymax}; scratch >= 4*256 doubles
+void bbox(const double *xy, int64_t N, double *scratch, double *bbox4, hipStream_t s);
+// keys[i] = Hilbert index of node i on a 2^16 x 2^16 lattice over the bbox (uniform scale), ids[i] = i
+void hilbert_keys(const double *xy, int64_t N, const double *bbox4, uint32_t *keys, uint32_t *ids, hipStream_t s);
+// perm = new->old (sorted ids).  Writes iperm (old->new), xyP[new] and maskP[new] = known_x | known_y<<1
+void apply_order(const uint32_t *perm, const double *xy, const uint8_t *u_known, int64_t N, int32_t *iperm,
+                 double *xyP, uint8_t *maskP, hipStream_t s);
+// per element corner k=3e+c: keys[k] = iperm[conn[k]], vals[k] = k, deg[key]++ ; out-of-range conn sets *err
+void incidence_keys(const int32_t *conn, int64_t E, const int32_t *iperm, int64_t N, uint32_t *keys,
+                    uint32_t *vals, int32_t *deg, int32_t *err, hipStream_t s);
+// tile_deg[t] = max deg over the tile's nodes; tile_cnt[t] = tile_deg[t] * B  (int64)
+void tile_degree(const int32_t *deg, int64_t N, int32_t B, int32_t T, int32_t *tile_deg, int64_t *tile_cnt,
+                 hipStream_t s);
+// ELL fill: slot k of node i (tile t, lane l) at ell[tile_off[t] + k*B + l] = (b, c) Hilbert ids of the
+// incident element's other two corners in cyclic order after i; (-1,-1) pads.
+void fill_ell(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn, const int32_t *iperm,
+              const int32_t *tile_deg, const int64_t *tile_off, int64_t N, int32_t B, int32_t T, int2 *ell,
+              hipStream_t s);
+// CSR pattern: 9 (row node, col node) pairs per element, key = row<<32 | col, val = 9e + 3a + b
+void csr_pairs(const int32_t *conn, int64_t E, uint64_t *keys, uint32_t *vals, hipStream_t s);
+// head[k] = 1 where sorted key k starts a new (row,col) block
+void csr_heads(const uint64_t *keys, int64_t n, int32_t *head, hipStream_t s);
+// for heads: seg_start[blk] = k, bcol[blk] = col node, rowcnt[row node]++   (blk = exclusive scan of head)
+void csr_segments(const uint64_t *keys, const int32_t *head, const int32_t *blk, int64_t n, int32_t *seg_start,
+                  int32_t *bcol, int32_t *rowcnt, hipStream_t s);
+// scalar CSR arrays of K from the node-block pattern
+void csr_export(const int32_t *bptr, const int32_t *bcol, int64_t N, int32_t *rowptr, int32_t *col, hipStream_t s);
+// free-DOF numbering flags: isfree[i] = !u_known[i]
+void free_flags(const uint8_t *u_known, int64_t n, int32_t *isfree, hipStream_t s);
+// K_ff row counts (exact zeros dropped) and fill, compact numbering
+void reduce_count(const int32_t *bptr, const int32_t *bcol, const double *kval, const uint8_t *u_known, int64_t N,
+                  int32_t *cnt /*2N*/, hipStream_t s);
+void reduce_fill(const int32_t *bptr, const int32_t *bcol, const double *kval, const uint8_t *u_known,
+                 const int32_t *fidx, const int32_t *rowoff /*2N, by full row*/, int64_t N, int32_t *rowptr_ff,
+                 int32_t *col_ff, double *val_ff, hipStream_t s);
+
+// --------------------------------------------------------------- exact.hip
+// solver.rs:263-278 per element, ke[36e + 6i + j]
+void element_stiffness(const double *xy, const int32_t *conn, int64_t E, double nu, double youngs, double thick,
+                       double *ke, hipStream_t s);
+// solver.rs:290-331 as an atomic-free gather: one thread per (row node, col node) block sums its segment of
+// sorted pairs in ascending element order into the four scalar CSR slots.
+void assemble_gather(const uint64_t *keys, const uint32_t *vals, const int32_t *seg_start, int64_t nb,
+                     const int32_t *bptr, const double *ke, double *kval, hipStream_t s);
+// solver.rs:365-404,427-432: b[row] = sum_{known cols, ascending} -(K*u) + f  (0 on prescribed rows),
+// written in Hilbert order: bP[2*iperm[node]+a]
+void rhs_from_csr(const int32_t *bptr, const int32_t *bcol, const double *kval, const uint8_t *u_known,
+                  const double *u_in, const double *f_in, const int32_t *iperm, int64_t N, double *bP,
+                  hipStream_t s);
+// same, compact numbering (for mag_reduce_system)
+void rhs_compact(const int32_t *bptr, const int32_t *bcol, const double *kval, const uint8_t *u_known,
+                 const double *u_in, const double *f_in, const int32_t *fidx, int64_t N, double *b, hipStream_t s);
+// solver.rs:443-454: u[2*perm[i]+a] = known ? u_in : xP[2i+a]
+void scatter_back(const double *xP, const uint32_t *perm, const uint8_t *u_known, const double *u_in, int64_t N,
+                  double *u, hipStream_t s);
+// solver.rs:456-469: f[i] = known ? K_row(i).u : f_in[i]
+void reactions_from_csr(const int32_t *bptr, const int32_t *bcol, const double *kval, const uint8_t *u_known,
+                        const double *u, const double *f_in, int64_t N, double *f, hipStream_t s);
+// matrix-free variant: f = known ? yP[iperm] : f_in
+void reactions_from_apply(const double *yP, const int32_t *iperm, const uint8_t *u_known, const double *f_in,
+                          int64_t N, double *f, hipStream_t s);
+// solver.rs:496-535
+void element_stress(const double *xy, const int32_t *conn, const double *u, int64_t E, double nu, double youngs,
+                    double *stress, hipStream_t s);
+
+// ------------------------------------------------------------------ cg.hip
+struct CgState {
+    double rr_hist[2]; // r.r of iterations k (slot k&1) and k-1
+    double target;     // absolute threshold on the cost
+    double final_cost;
+    double bb;         // b.b
+    double alpha_last;
+    long long iterA;   // written by the update kernel, read by the operator kernel
+    long long iterB;   // written by the operator kernel, read by the update kernel
+    long long iterations;
+    long long max_iter;
+    int done;
+    int converged;
+    int breakdown;
+    int stop_mode;
+    double tol;
+    double pad[3];
+};
+
+struct OpParams {
+    int64_t N;
+    int32_t T; // tiles
+    int32_t nPart;
+    const double2 *xyP;
+    const uint8_t *maskP;
+    const int32_t *tile_deg;
+    const int64_t *tile_off;
+    const int2 *ell;
+    double c0, nu, h; // E t / (2 (1-nu^2)), nu, (1-nu)/2
+    // CG mode
+    const double2 *r;
+    const double2 *pprev;
+    double2 *pnew;
+    double2 *q;
+    const double *partRR;
+    double *partPQ;
+    CgState *st;
+    double *hist;
+    int32_t hist_len;
+    // plain mode: y = [M] K [M] v
+    int32_t masked;
+    const double2 *v;
+    double2 *y;
+};
+
+struct UpdParams {
+    int64_t N;
+    int32_t T;
+    int32_t nPart;
+    double2 *x;
+    double2 *r;
+    const double2 *p;
+    const double2 *q;
+    const double *partPQ;
+    double *partRR;
+    CgState *st;
+};
+
+int cg_grid(int32_t T);
+// operator kernel, B in {256,512,1024}; cg_mode: p = -r + beta*pprev fused, writes pnew, q, partPQ
+void op_launch(const OpParams &P, int32_t B, bool cg_mode, hipStream_t s);
+void upd_launch(const UpdParams &P, int32_t B, hipStream_t s);
+// r = -bP, x = 0 handled by caller memset; writes partRR
+void cg_init(const double2 *bP, double2 *r, int64_t N, int32_t B, int32_t T, double *partRR, hipStream_t s);
+// one block: bb = sum(partRR), thresholds, counters
+void cg_setup(const double *partRR, int32_t nPart, int stop_mode, double tol, long long max_iter, CgState *st,
+              hipStream_t s);
+// vP[2*iperm[i]+a] = (mask? !known : 1) * v[2i+a]  /  y[2i+a] = yP[2*iperm[i]+a]
+void to_hilbert(const double *v, const int32_t *iperm, const uint8_t *u_known, int32_t masked, int64_t N, double *vP,
+                hipStream_t s);
+void from_hilbert(const double *yP, const int32_t *iperm, int64_t N, double *y, hipStream_t s);
+// uext[2*iperm[i]+a] = known ? u_in : 0
+void known_to_hilbert(const double *u_in, const uint8_t *u_known, const int32_t *iperm, int64_t N, double *uP,
+                      hipStream_t s);
+// bP = free ? f_in - yP : 0 (Hilbert order)
+void rhs_from_apply(const double *yP, const double *f_in, const uint8_t *u_known, const uint32_t *perm, int64_t N,
+                    double *bP, hipStream_t s);
+
+} // namespace magk

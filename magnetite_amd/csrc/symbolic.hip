@@ -1,0 +1,378 @@
+// Integer kernels of the one-time symbolic phases (no reference counterpart:
+// the reference scatters into a dense n x n matrix, solver.rs:295-325).
+//   * Hilbert ordering of nodes  -> contiguous runs of B nodes are compact tiles
+//   * node -> incident (element, corner) lists, ascending element order
+//   * per-tile ELL table of the other two corners of every incident element
+//   * node-block CSR pattern of K in the caller's numbering, ascending columns
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+
+namespace magk {
+
+static inline int blocks_for(int64_t n, int threads, int cap = 1 << 30)
+{
+    int64_t b = (n + threads - 1) / threads;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+// ---------------------------------------------------------------- bbox ---
+__device__ inline void wave_minmax(double &lo, double &hi)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = fmin(lo, __shfl_down(lo, off));
+        hi = fmax(hi, __shfl_down(hi, off));
+    }
+}
+
+__global__ void __launch_bounds__(256) k_bbox_partial(const double2 *xy, int64_t N, double *part)
+{
+    __shared__ double s[4][4];
+    double xlo = 1.0e308, ylo = 1.0e308, xhi = -1.0e308, yhi = -1.0e308;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+        const double2 c = xy[i];
+        xlo = fmin(xlo, c.x);
+        xhi = fmax(xhi, c.x);
+        ylo = fmin(ylo, c.y);
+        yhi = fmax(yhi, c.y);
+    }
+    wave_minmax(xlo, xhi);
+    wave_minmax(ylo, yhi);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s[w][0] = xlo;
+        s[w][1] = ylo;
+        s[w][2] = xhi;
+        s[w][3] = yhi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) {
+            s[0][0] = fmin(s[0][0], s[k][0]);
+            s[0][1] = fmin(s[0][1], s[k][1]);
+            s[0][2] = fmax(s[0][2], s[k][2]);
+            s[0][3] = fmax(s[0][3], s[k][3]);
+        }
+        for (int k = 0; k < 4; ++k) part[4 * blockIdx.x + k] = s[0][k];
+    }
+}
+
+__global__ void k_bbox_final(const double *part, int nblocks, double *bbox4)
+{
+    if (threadIdx.x == 0) {
+        double b[4] = {part[0], part[1], part[2], part[3]};
+        for (int k = 1; k < nblocks; ++k) {
+            b[0] = fmin(b[0], part[4 * k]);
+            b[1] = fmin(b[1], part[4 * k + 1]);
+            b[2] = fmax(b[2], part[4 * k + 2]);
+            b[3] = fmax(b[3], part[4 * k + 3]);
+        }
+        for (int k = 0; k < 4; ++k) bbox4[k] = b[k];
+    }
+}
+
+void bbox(const double *xy, int64_t N, double *scratch, double *bbox4, hipStream_t s)
+{
+    const int nb = blocks_for(N, 256, 256);
+    k_bbox_partial<<<nb, 256, 0, s>>>((const double2 *)xy, N, scratch);
+    k_bbox_final<<<1, 64, 0, s>>>(scratch, nb, bbox4);
+}
+
+// ------------------------------------------------------------- Hilbert ---
+__device__ inline uint32_t hilbert16(uint32_t x, uint32_t y)
+{
+    uint32_t d = 0;
+    for (uint32_t s = 1u << (kHilbertBits - 1); s > 0; s >>= 1) {
+        const uint32_t rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+        d += s * s * ((3u * rx) ^ ry);
+        if (ry == 0) {
+            if (rx == 1) {
+                x = ((1u << kHilbertBits) - 1u) - x;
+                y = ((1u << kHilbertBits) - 1u) - y;
+            }
+            const uint32_t t = x;
+            x = y;
+            y = t;
+        }
+    }
+    return d;
+}
+
+__global__ void __launch_bounds__(256) k_hilbert_keys(const double2 *xy, int64_t N, const double *bbox4,
+                                                      uint32_t *keys, uint32_t *ids)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const double x0 = bbox4[0], y0 = bbox4[1];
+    const double ext = fmax(bbox4[2] - x0, bbox4[3] - y0);
+    const double sc = ext > 0.0 ? 65535.0 / ext : 0.0; // one scale for both axes: tiles stay square
+    const double2 c = xy[i];
+    double fx = (c.x - x0) * sc, fy = (c.y - y0) * sc;
+    // NaN/inf coordinates must not index out of range
+    fx = (fx >= 0.0 && fx <= 65535.0) ? fx : 0.0;
+    fy = (fy >= 0.0 && fy <= 65535.0) ? fy : 0.0;
+    keys[i] = hilbert16((uint32_t)fx, (uint32_t)fy);
+    ids[i] = (uint32_t)i;
+}
+
+void hilbert_keys(const double *xy, int64_t N, const double *bbox4, uint32_t *keys, uint32_t *ids, hipStream_t s)
+{
+    k_hilbert_keys<<<blocks_for(N, 256), 256, 0, s>>>((const double2 *)xy, N, bbox4, keys, ids);
+}
+
+__global__ void __launch_bounds__(256) k_apply_order(const uint32_t *perm, const double2 *xy, const uint8_t *u_known,
+                                                     int64_t N, int32_t *iperm, double2 *xyP, uint8_t *maskP)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t o = perm[i];
+    iperm[o] = (int32_t)i;
+    xyP[i] = xy[o];
+    maskP[i] = (uint8_t)((u_known[2 * (int64_t)o] ? 1 : 0) | (u_known[2 * (int64_t)o + 1] ? 2 : 0));
+}
+
+void apply_order(const uint32_t *perm, const double *xy, const uint8_t *u_known, int64_t N, int32_t *iperm,
+                 double *xyP, uint8_t *maskP, hipStream_t s)
+{
+    k_apply_order<<<blocks_for(N, 256), 256, 0, s>>>(perm, (const double2 *)xy, u_known, N, iperm, (double2 *)xyP,
+                                                     maskP);
+}
+
+// ----------------------------------------------------------- incidence ---
+__global__ void __launch_bounds__(256) k_incidence_keys(const int32_t *conn, int64_t n3, const int32_t *iperm,
+                                                        int64_t N, uint32_t *keys, uint32_t *vals, int32_t *deg,
+                                                        int32_t *err)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n3) return;
+    int32_t n = conn[k];
+    if (n < 0 || (int64_t)n >= N) {
+        atomicOr(err, 1);
+        n = 0;
+    }
+    const int32_t g = iperm[n];
+    keys[k] = (uint32_t)g;
+    vals[k] = (uint32_t)k;
+    atomicAdd(&deg[g], 1);
+}
+
+void incidence_keys(const int32_t *conn, int64_t E, const int32_t *iperm, int64_t N, uint32_t *keys, uint32_t *vals,
+                    int32_t *deg, int32_t *err, hipStream_t s)
+{
+    k_incidence_keys<<<blocks_for(3 * E, 256), 256, 0, s>>>(conn, 3 * E, iperm, N, keys, vals, deg, err);
+}
+
+__global__ void __launch_bounds__(256) k_tile_degree(const int32_t *deg, int64_t N, int32_t B, int32_t *tile_deg,
+                                                     int64_t *tile_cnt)
+{
+    __shared__ int s[4];
+    const int64_t base = (int64_t)blockIdx.x * B;
+    int m = 0;
+    for (int l = threadIdx.x; l < B; l += 256) {
+        const int64_t i = base + l;
+        if (i < N) m = max(m, deg[i]);
+    }
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_down(m, off));
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(s[0], s[1]), max(s[2], s[3]));
+        tile_deg[blockIdx.x] = m;
+        tile_cnt[blockIdx.x] = (int64_t)m * B;
+    }
+}
+
+void tile_degree(const int32_t *deg, int64_t N, int32_t B, int32_t T, int32_t *tile_deg, int64_t *tile_cnt,
+                 hipStream_t s)
+{
+    k_tile_degree<<<T, 256, 0, s>>>(deg, N, B, tile_deg, tile_cnt);
+}
+
+__global__ void __launch_bounds__(256) k_fill_ell(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn,
+                                                  const int32_t *iperm, const int32_t *tile_deg,
+                                                  const int64_t *tile_off, int64_t N, int32_t B, int2 *ell)
+{
+    const int32_t t = blockIdx.x;
+    const int32_t td = tile_deg[t];
+    int2 *dst = ell + tile_off[t];
+    for (int l = threadIdx.x; l < B; l += 256) {
+        const int64_t i = (int64_t)t * B + l;
+        int32_t o = 0, d = 0;
+        if (i < N) {
+            o = inc_off[i];
+            d = inc_off[i + 1] - o;
+        }
+        for (int k = 0; k < td; ++k) {
+            int2 bc = make_int2(-1, -1);
+            if (k < d) {
+                const uint32_t v = inc[o + k];
+                const uint32_t e = v / 3u, c = v - 3u * e;
+                const uint32_t c1 = c == 2 ? 0 : c + 1, c2 = c1 == 2 ? 0 : c1 + 1;
+                bc.x = iperm[conn[3 * (int64_t)e + c1]];
+                bc.y = iperm[conn[3 * (int64_t)e + c2]];
+            }
+            dst[(int64_t)k * B + l] = bc;
+        }
+    }
+}
+
+void fill_ell(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn, const int32_t *iperm,
+              const int32_t *tile_deg, const int64_t *tile_off, int64_t N, int32_t B, int32_t T, int2 *ell,
+              hipStream_t s)
+{
+    k_fill_ell<<<T, 256, 0, s>>>(inc_off, inc, conn, iperm, tile_deg, tile_off, N, B, ell);
+}
+
+// --------------------------------------------------------- CSR pattern ---
+__global__ void __launch_bounds__(256) k_csr_pairs(const int32_t *conn, int64_t n9, uint64_t *keys, uint32_t *vals)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n9) return;
+    const int64_t e = k / 9;
+    const int ab = (int)(k - 9 * e);
+    const int a = ab / 3, b = ab - 3 * a;
+    keys[k] = ((uint64_t)(uint32_t)conn[3 * e + a] << 32) | (uint64_t)(uint32_t)conn[3 * e + b];
+    vals[k] = (uint32_t)k;
+}
+
+void csr_pairs(const int32_t *conn, int64_t E, uint64_t *keys, uint32_t *vals, hipStream_t s)
+{
+    k_csr_pairs<<<blocks_for(9 * E, 256), 256, 0, s>>>(conn, 9 * E, keys, vals);
+}
+
+__global__ void __launch_bounds__(256) k_csr_heads(const uint64_t *keys, int64_t n, int32_t *head)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    head[k] = (k == 0 || keys[k] != keys[k - 1]) ? 1 : 0;
+}
+
+void csr_heads(const uint64_t *keys, int64_t n, int32_t *head, hipStream_t s)
+{
+    k_csr_heads<<<blocks_for(n, 256), 256, 0, s>>>(keys, n, head);
+}
+
+__global__ void __launch_bounds__(256) k_csr_segments(const uint64_t *keys, const int32_t *head, const int32_t *blk,
+                                                      int64_t n, int32_t *seg_start, int32_t *bcol, int32_t *rowcnt)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    if (head[k]) {
+        const int32_t b = blk[k];
+        const uint64_t key = keys[k];
+        seg_start[b] = (int32_t)k;
+        bcol[b] = (int32_t)(key & 0xffffffffu);
+        atomicAdd(&rowcnt[(int32_t)(key >> 32)], 1);
+    }
+    if (k == n - 1) seg_start[blk[k] + head[k]] = (int32_t)n;
+}
+
+void csr_segments(const uint64_t *keys, const int32_t *head, const int32_t *blk, int64_t n, int32_t *seg_start,
+                  int32_t *bcol, int32_t *rowcnt, hipStream_t s)
+{
+    k_csr_segments<<<blocks_for(n, 256), 256, 0, s>>>(keys, head, blk, n, seg_start, bcol, rowcnt);
+}
+
+// rows 2i and 2i+1 share node i's block pattern: row 2i holds (2j,2j+1) for each j, then row 2i+1 the same.
+__global__ void __launch_bounds__(256) k_csr_export(const int32_t *bptr, const int32_t *bcol, int64_t N,
+                                                    int32_t *rowptr, int32_t *col)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int32_t p = bptr[i], cnt = bptr[i + 1] - p;
+    rowptr[2 * i] = 4 * p;
+    rowptr[2 * i + 1] = 4 * p + 2 * cnt;
+    if (i == N - 1) rowptr[2 * N] = 4 * bptr[N];
+    for (int k = 0; k < cnt; ++k) {
+        const int32_t j = bcol[p + k];
+        col[4 * (int64_t)p + 2 * k] = 2 * j;
+        col[4 * (int64_t)p + 2 * k + 1] = 2 * j + 1;
+        col[4 * (int64_t)p + 2 * cnt + 2 * k] = 2 * j;
+        col[4 * (int64_t)p + 2 * cnt + 2 * k + 1] = 2 * j + 1;
+    }
+}
+
+void csr_export(const int32_t *bptr, const int32_t *bcol, int64_t N, int32_t *rowptr, int32_t *col, hipStream_t s)
+{
+    k_csr_export<<<blocks_for(N, 256), 256, 0, s>>>(bptr, bcol, N, rowptr, col);
+}
+
+// --------------------------------------------- K_ff (solver.rs:365-404) ---
+__global__ void __launch_bounds__(256) k_free_flags(const uint8_t *u_known, int64_t n, int32_t *isfree)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i <= n) isfree[i] = (i < n && !u_known[i]) ? 1 : 0; // entry n is the scan's sentinel
+}
+
+void free_flags(const uint8_t *u_known, int64_t n, int32_t *isfree, hipStream_t s)
+{
+    k_free_flags<<<blocks_for(n + 1, 256), 256, 0, s>>>(u_known, n, isfree);
+}
+
+__global__ void __launch_bounds__(256) k_reduce_count(const int32_t *bptr, const int32_t *bcol, const double *kval,
+                                                      const uint8_t *u_known, int64_t N, int32_t *cnt)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r > 2 * N) return;
+    int32_t c = 0;
+    if (r < 2 * N && !u_known[r]) {
+        const int64_t i = r >> 1;
+        const int a = (int)(r & 1);
+        const int32_t p = bptr[i], nb = bptr[i + 1] - p;
+        const double *row = kval + 4 * (int64_t)p + (int64_t)a * 2 * nb;
+        for (int k = 0; k < nb; ++k) {
+            const int64_t j = bcol[p + k];
+            c += (!u_known[2 * j] && row[2 * k] != 0.0) ? 1 : 0;
+            c += (!u_known[2 * j + 1] && row[2 * k + 1] != 0.0) ? 1 : 0;
+        }
+    }
+    cnt[r] = c; // entry 2N is the scan's sentinel (0)
+}
+
+void reduce_count(const int32_t *bptr, const int32_t *bcol, const double *kval, const uint8_t *u_known, int64_t N,
+                  int32_t *cnt, hipStream_t s)
+{
+    k_reduce_count<<<blocks_for(2 * N + 1, 256), 256, 0, s>>>(bptr, bcol, kval, u_known, N, cnt);
+}
+
+__global__ void __launch_bounds__(256) k_reduce_fill(const int32_t *bptr, const int32_t *bcol, const double *kval,
+                                                     const uint8_t *u_known, const int32_t *fidx,
+                                                     const int32_t *rowoff, int64_t N, int32_t *rowptr_ff,
+                                                     int32_t *col_ff, double *val_ff)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= 2 * N) return;
+    if (r == 2 * N - 1) rowptr_ff[fidx[2 * N]] = rowoff[2 * N];
+    if (u_known[r]) return;
+    const int64_t i = r >> 1;
+    const int a = (int)(r & 1);
+    const int32_t p = bptr[i], nb = bptr[i + 1] - p;
+    const double *row = kval + 4 * (int64_t)p + (int64_t)a * 2 * nb;
+    int64_t q = rowoff[r];
+    rowptr_ff[fidx[r]] = (int32_t)q;
+    for (int k = 0; k < nb; ++k) {
+        const int64_t j = bcol[p + k];
+        for (int bq = 0; bq < 2; ++bq) {
+            const double v = row[2 * k + bq];
+            if (!u_known[2 * j + bq] && v != 0.0) {
+                col_ff[q] = fidx[2 * j + bq];
+                val_ff[q] = v;
+                ++q;
+            }
+        }
+    }
+}
+
+void reduce_fill(const int32_t *bptr, const int32_t *bcol, const double *kval, const uint8_t *u_known,
+                 const int32_t *fidx, const int32_t *rowoff, int64_t N, int32_t *rowptr_ff, int32_t *col_ff,
+                 double *val_ff, hipStream_t s)
+{
+    k_reduce_fill<<<blocks_for(2 * N, 256), 256, 0, s>>>(bptr, bcol, kval, u_known, fidx, rowoff, N, rowptr_ff,
+                                                        col_ff, val_ff);
+}
+
+} // namespace magk
