@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config, one JSON line on rank 0.
+
+A "step" is one full pass of the hot path (mag_run: node ordering, K_e build, CSR assembly, BC elimination,
+matrix-free CG to the configured tolerance, reactions, stress -- solver.rs:548-583) over a synthetic mesh
+whose flat arrays are already resident in HBM (mag_upload happens before the timed region).
+
+  N = 1 : BASELINE config 3, the configuration the metric is quoted on: ~1M-triangle plate with a hole,
+          left edge fixed, right edge ux = delta, CG to relative residual 1e-8.
+  N > 1 : weak scaling -- every GPU owns ~1M triangles of one global plate N times as tall (strips along y,
+          one RCCL all-reduce of [halo residual | dot partials] per CG kernel pair).
+
+value = elements of the global mesh * steps / wall time of the timed region (max over ranks).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def build_problem(workload, n_gpus):
+    import numpy as np
+
+    from magnetite_amd import meshgen
+    if workload == "hole1m":
+        n = meshgen.grid_for_triangles(1e6, np.pi * 0.15 ** 2)
+        if n_gpus == 1:
+            mesh = meshgen.plate_with_holes(n)
+        else:  # the same plate stacked n_gpus times along y, one hole per unit square
+            holes = [(0.5, (k + 0.5) / n_gpus, 0.15) for k in range(n_gpus)]
+            mesh = meshgen.plate_with_holes(n, n * n_gpus, 1.0, float(n_gpus), holes=holes)
+        return meshgen.config_fixed_left_pull_right(mesh), f"plate-with-hole {n}x{n * n_gpus} cells"
+    if workload == "plate100k":
+        return meshgen.config_fixed_left_point_load(meshgen.plate(224, 224 * n_gpus, 1.0, float(n_gpus))), "plate 224^2"
+    if workload == "plate4m":
+        return meshgen.config_fixed_left_pull_right(meshgen.plate(1414, 1414 * n_gpus, 1.0, float(n_gpus))), "plate 1414^2"
+    if workload == "multihole16m":
+        n = meshgen.grid_for_triangles(16e6, np.pi * 0.25 ** 2)
+        return meshgen.config_fixed_left_pull_right(meshgen.multi_hole(n, 4, 0.25)), f"multi-hole {n}^2"
+    raise SystemExit(f"unknown workload {workload}")
+
+
+def cpu_baseline(prob, gpu_iterations, stop_mode, tol, sample_iters):
+    """Oracle (C restatement of solver.rs, sparse path, 1 thread) timed on a bounded sample of the same workload:
+    full K_e + CSR assembly + BC elimination, then `sample_iters` CG iterations; CG time is scaled to the
+    iteration count the GPU needed (the oracle runs the same recurrence)."""
+    import oracle
+    t0 = time.perf_counter()
+    K = oracle.assemble_sparse(prob.xy_flat, prob.conn_flat, prob.poisson_ratio, prob.youngs_modulus,
+                               prob.part_thickness)
+    A, b = oracle.reduce_system(K, prob.u_known, prob.u_in, prob.f_in)
+    t1 = time.perf_counter()
+    _, it, _, _ = oracle.cg(A, b, stop_mode=stop_mode, tol=tol, max_iter=sample_iters)
+    t2 = time.perf_counter()
+    per_iter = (t2 - t1) / max(it, 1)
+    total = (t1 - t0) + per_iter * gpu_iterations
+    E = prob.mesh.num_elements
+    return {
+        "value": E / total, "unit": "elements/s", "cores": 1, "kind": "port",
+        "sample": f"oracle/magnetite_oracle.c on the same mesh: full K_e+CSR assembly+BC elimination "
+                  f"({t1 - t0:.2f} s) + {it} CG iterations ({per_iter * 1e3:.2f} ms each), CG scaled to the "
+                  f"{gpu_iterations} iterations of the GPU solve",
+        "assembly_elements_per_s": E / (t1 - t0), "cg_iters_per_s": 1.0 / per_iter,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="hole1m")
+    ap.add_argument("--tol", type=float, default=1e-8)
+    ap.add_argument("--stop", default="rel", choices=["rel", "rnorm", "rnorm_sq"])
+    ap.add_argument("--tile", type=int, default=512)
+    ap.add_argument("--check-every", type=int, default=64)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-iters", type=int, default=150)
+    ap.add_argument("--op-reps", type=int, default=400)
+    args = ap.parse_args()
+
+    import torch  # first: libmagnetite_hip.so then shares torch's HIP runtime and RCCL (same SONAMEs)
+    import torch.distributed as dist
+
+    from magnetite_amd import Context, _lib
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the solver has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    stop_mode = {"rel": _lib.MAG_STOP_REL, "rnorm": _lib.MAG_STOP_RNORM, "rnorm_sq": _lib.MAG_STOP_RNORM_SQ}[args.stop]
+    prob, desc = build_problem(args.workload, world)
+    E, N = prob.mesh.num_elements, prob.mesh.num_nodes
+
+    ctx = Context(device=local_rank, stop_mode=stop_mode, tol=args.tol, tile_nodes=args.tile,
+                  check_every=args.check_every, use_graph=0 if args.no_graph else 1)
+    if world > 1:
+        ctx.init_rccl_from_torch(dist, rank, world)
+    ctx.upload_problem(prob)  # inputs resident in HBM before the timed region
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.run()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    st = ctx.stats()
+    ms_op = ctx.time_operator(args.op_reps)  # HIP events on the library's stream around op_reps launches
+    u, _, _ = ctx.download()
+
+    if rank == 0:
+        iters = int(st["iterations"])
+        ms_step = elapsed * 1e3 / args.steps
+        Eloc, Nloc = E / world, N / world  # per-GPU share the operator kernel processes per launch
+        spmv_bytes = 12.0 * Eloc + 50.0 * Nloc          # matrix-free SpMV
+        iter_bytes = 12.0 * Eloc + 242.0 * Nloc         # full CG iteration
+        achieved = spmv_bytes / (ms_op * 1e-3) / 1e9
+        asm_ms = st["ms_element"] + st["ms_assemble"] + st["ms_bc"]
+        out = {
+            "metric": "elements/sec assembly + CG iters/sec (achieved HBM GB/s), 1M-tri mesh",
+            "value": E * args.steps / elapsed, "unit": "elements/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {desc}, {E} triangles, {N} nodes, left edge fixed, "
+                                   f"right edge ux=delta; full solver::run per step; CG stop={args.stop} tol={args.tol:g}",
+                       "elements": E, "nodes": N, "tile_nodes": args.tile, "cg_stop": args.stop, "cg_tol": args.tol,
+                       "parallelism": f"strips{world}" if world > 1 else "single"},
+            "roofline": {"bound": "hbm", "kernel": "k_operator<%d,true> (matrix-free SpMV fused with p-update and p.q)" % args.tile,
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "bytes_per_launch": spmv_bytes, "us_per_launch": ms_op * 1e3},
+            "cg_iterations": iters, "cg_converged": int(st["converged"]), "cg_final_cost": st["final_cost"],
+            "cg_iters_per_sec": iters / (st["ms_cg"] * 1e-3) if st["ms_cg"] > 0 else None,
+            "cg_iteration_gbps": iter_bytes * iters / (st["ms_cg"] * 1e-3) / 1e9 if st["ms_cg"] > 0 else None,
+            "assembly_elements_per_sec": Eloc / (asm_ms * 1e-3) if asm_ms > 0 else None,
+            "phases_ms": {k: st[k] for k in ("ms_order", "ms_csr_symbolic", "ms_element", "ms_assemble", "ms_bc",
+                                             "ms_cg", "ms_post", "ms_total")},
+            "u_max": float(abs(u).max()),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(prob, iters, stop_mode, args.tol, args.cpu_sample_iters)
+            out["cpu_baseline"]["cores_available"] = os.cpu_count()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

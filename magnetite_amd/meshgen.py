@@ -194,8 +194,11 @@ def perturb(mesh, amount, seed=12345):
     a = mesh.xy[mesh.conn]
     h = np.sqrt(np.abs(np.mean(0.5 * ((a[:, 1, 0] - a[:, 0, 0]) * (a[:, 2, 1] - a[:, 0, 1]) -
                                       (a[:, 2, 0] - a[:, 0, 0]) * (a[:, 1, 1] - a[:, 0, 1]))) * 2.0))
-    xy = mesh.xy + rng.uniform(-amount * h, amount * h, size=mesh.xy.shape)
-    return Mesh(xy, mesh.conn.copy(), mesh.name + "_pert")
+    d = rng.uniform(-amount * h, amount * h, size=mesh.xy.shape)
+    lo, hi = mesh.xy.min(axis=0), mesh.xy.max(axis=0)
+    edge = (np.abs(mesh.xy - lo) < 1e-12 * (hi - lo)).any(axis=1) | (np.abs(mesh.xy - hi) < 1e-12 * (hi - lo)).any(axis=1)
+    d[edge] = 0.0  # outer boundary stays put so edge rules still catch it
+    return Mesh(mesh.xy + d, mesh.conn.copy(), mesh.name + "_pert")
 
 
 def clockwise(mesh):

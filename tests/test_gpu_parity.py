@@ -105,7 +105,10 @@ def test_full_solve_parity(built, name, assemble):
     k = p.u_known == 1
     assert np.array_equal(out["u"][k], p.u_in[k])
     assert np.array_equal(out["f"][~k], p.f_in[~k])
-    assert rel(out["f"][k], ref["f"][k]) <= 1e-7
+    # reactions are sums of O(|K||u|) terms that may cancel to round-off: absolute bar on that scale
+    fscale = np.abs(oracle.element_stiffness_all(p.xy_flat, p.conn_flat, p.poisson_ratio, p.youngs_modulus,
+                                                 p.part_thickness)).max() * np.abs(ref["u"]).max()
+    assert np.abs(out["f"][k] - ref["f"][k]).max() <= 1e-8 * fscale
     # first iterations follow the oracle's residual history (argmin recurrences)
     n = min(len(hist), len(ref["history"]), 8)
     assert np.allclose(hist[:n], ref["history"][:n], rtol=1e-9)
