@@ -86,7 +86,9 @@ typedef struct mag_options {
     int32_t tile_nodes;   /* owned nodes per workgroup tile: 256 | 512 (default) | 1024    */
     int32_t history_len;  /* keep the cost of the first history_len iterations (tests)     */
     int32_t verbose;      /* 1: print the reference's "info:" phase lines to stdout        */
-    int32_t reserved[5];
+    int32_t op_variant;   /* 0 (default): LDS-halo operator when every tile fits LDS, else the
+                             global-gather operator; 1: always the global-gather operator  */
+    int32_t reserved[4];
 } mag_options;
 
 /* Borrowed view of the caller's flattened Vec<Node>/Vec<Element>/ModelMetadata
@@ -126,6 +128,9 @@ typedef struct mag_stats {
     int64_t nnz;        /* scalar nnz of K (0 if not assembled) */
     int64_t num_tiles;
     int64_t ell_entries; /* (node,incident element) slots incl. padding */
+    int64_t halo_nodes;  /* sum over tiles of nodes staged from other tiles */
+    int32_t max_tile_halo;
+    int32_t lds_operator; /* 1: LDS-halo operator ran, 0: global-gather fallback */
     /* per-phase device time, HIP events on the context's stream, milliseconds */
     double ms_order;     /* Hilbert ordering + incidence + tile tables (symbolic, matrix-free op) */
     double ms_csr_symbolic;

@@ -5,8 +5,10 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include <hip/hip_runtime.h>
 
@@ -75,6 +77,12 @@ struct mag_ctx {
     DevBuf scratch, small; // rocPRIM temp; small = bbox partials, bbox, err flag
     DevBuf sK0, sK1, sV0, sV1;
     DevBuf perm, iperm, xyP, maskP, deg, inc_off, inc, tile_deg, tile_cnt, tile_off, ell;
+    // tile-local numbering for the LDS-halo operator
+    bool use_lds = false;
+    int tune_wt = 1; // write-through stores in the CG kernels (MAG_TUNE_WT=0 to compare)
+    int32_t cap = 0, max_halo = 0;
+    int64_t halo_total = 0;
+    DevBuf hcnt, hoffn, hk0, hk1, halo_g, tile_hcnt, tile_hoff;
 
     // CSR of K (caller numbering)
     int64_t nb = 0;
@@ -86,7 +94,7 @@ struct mag_ctx {
     DevBuf x, r, p0, p1, q, bP, tmpP, partRR, partPQ, state, hist;
     hipGraphExec_t graph = nullptr;
     struct GraphKey {
-        void *ptrs[16];
+        void *ptrs[20];
         int64_t N;
         int32_t T, B, G, hist_len;
     } gkey = {};
@@ -223,17 +231,75 @@ int ensure_order(mag_ctx *ctx)
     magk::tile_degree(ctx->deg.as<int32_t>(), N, B, T, ctx->tile_deg.as<int32_t>(), ctx->tile_cnt.as<int64_t>(), s);
     if (int rc = scan_i64(ctx, ctx->tile_cnt.as<int64_t>(), ctx->tile_off.as<int64_t>(), (size_t)T + 1)) return rc;
 
-    int32_t h_err = 0;
+    // tile-local numbering: references of every node to nodes of other tiles
+    HIPCHK(ctx->hcnt.reserve(4 * ((size_t)N + 1)));
+    HIPCHK(ctx->hoffn.reserve(4 * ((size_t)N + 1)));
+    HIPCHK(ctx->tile_hcnt.reserve(4 * ((size_t)T + 1)));
+    HIPCHK(ctx->tile_hoff.reserve(4 * ((size_t)T + 1)));
+    magk::halo_count(ctx->inc_off.as<int32_t>(), ctx->inc.as<uint32_t>(), ctx->conn.as<int32_t>(),
+                     ctx->iperm.as<int32_t>(), N, B, ctx->hcnt.as<int32_t>(), s);
+    if (int rc = scan_i32(ctx, ctx->hcnt.as<int32_t>(), ctx->hoffn.as<int32_t>(), (size_t)N + 1)) return rc;
+
+    int32_t h_err = 0, h_refs = 0;
     int64_t h_total = 0;
     HIPCHK(hipMemcpyAsync(&h_err, errflag, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&h_total, ctx->tile_off.as<int64_t>() + T, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&h_refs, ctx->hoffn.as<int32_t>() + N, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (h_err) return fail(ctx, MAG_ERR_BAD_ARGS, "element node index out of range [0, %lld)", (long long)N);
     ctx->ell_total = h_total;
-    HIPCHK(ctx->ell.reserve(8 * (size_t)(h_total > 0 ? h_total : 1)));
-    magk::fill_ell(ctx->inc_off.as<int32_t>(), ctx->inc.as<uint32_t>(), ctx->conn.as<int32_t>(),
-                   ctx->iperm.as<int32_t>(), ctx->tile_deg.as<int32_t>(), ctx->tile_off.as<int64_t>(), N, B, T,
-                   ctx->ell.as<int2>(), s);
+
+    HIPCHK(hipMemsetAsync(ctx->tile_hcnt.p, 0, 4 * ((size_t)T + 1), s));
+    int32_t max_halo = 0;
+    ctx->halo_total = 0;
+    if (h_refs > 0) {
+        const size_t nr = (size_t)h_refs;
+        HIPCHK(ctx->hk0.reserve(8 * nr));
+        HIPCHK(ctx->hk1.reserve(8 * nr));
+        HIPCHK(ctx->head.reserve(4 * nr));
+        HIPCHK(ctx->blk.reserve(4 * nr));
+        HIPCHK(ctx->halo_g.reserve(4 * nr));
+        magk::halo_emit(ctx->inc_off.as<int32_t>(), ctx->inc.as<uint32_t>(), ctx->conn.as<int32_t>(),
+                        ctx->iperm.as<int32_t>(), N, B, ctx->hoffn.as<int32_t>(), ctx->hk0.as<uint64_t>(), s);
+        {
+            size_t tb = 0;
+            const int end_bit = 32 + ceil_log2(T);
+            HIPCHK(magp::sort_keys_u64(nullptr, &tb, ctx->hk0.as<uint64_t>(), ctx->hk1.as<uint64_t>(), nr, 0, end_bit, s));
+            if (int rc = scratch_for(ctx, tb)) return rc;
+            HIPCHK(magp::sort_keys_u64(ctx->scratch.p, &tb, ctx->hk0.as<uint64_t>(), ctx->hk1.as<uint64_t>(), nr, 0,
+                                       end_bit, s));
+        }
+        magk::csr_heads(ctx->hk1.as<uint64_t>(), (int64_t)nr, ctx->head.as<int32_t>(), s);
+        if (int rc = scan_i32(ctx, ctx->head.as<int32_t>(), ctx->blk.as<int32_t>(), nr)) return rc;
+        magk::halo_unique(ctx->hk1.as<uint64_t>(), ctx->head.as<int32_t>(), ctx->blk.as<int32_t>(), (int64_t)nr,
+                          ctx->halo_g.as<int32_t>(), ctx->tile_hcnt.as<int32_t>(), s);
+    } else {
+        HIPCHK(ctx->halo_g.reserve(64));
+    }
+    if (int rc = scan_i32(ctx, ctx->tile_hcnt.as<int32_t>(), ctx->tile_hoff.as<int32_t>(), (size_t)T + 1)) return rc;
+    {
+        std::vector<int32_t> hc((size_t)T + 1);
+        HIPCHK(hipMemcpyAsync(hc.data(), ctx->tile_hcnt.p, 4 * ((size_t)T + 1), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (int32_t t = 0; t < T; ++t) {
+            if (hc[t] > max_halo) max_halo = hc[t];
+            ctx->halo_total += hc[t];
+        }
+    }
+    ctx->max_halo = max_halo;
+    ctx->cap = ((B + max_halo + 31) / 32) * 32;
+    ctx->use_lds = ctx->opt.op_variant != 1 && ctx->cap <= magk::kMaxLdsNodes;
+    if (ctx->use_lds) {
+        HIPCHK(ctx->ell.reserve(4 * (size_t)(h_total > 0 ? h_total : 1)));
+        magk::fill_ell16(ctx->inc_off.as<int32_t>(), ctx->inc.as<uint32_t>(), ctx->conn.as<int32_t>(),
+                         ctx->iperm.as<int32_t>(), ctx->tile_deg.as<int32_t>(), ctx->tile_off.as<int64_t>(),
+                         ctx->tile_hoff.as<int32_t>(), ctx->halo_g.as<int32_t>(), N, B, T, ctx->ell.as<uint32_t>(), s);
+    } else {
+        HIPCHK(ctx->ell.reserve(8 * (size_t)(h_total > 0 ? h_total : 1)));
+        magk::fill_ell(ctx->inc_off.as<int32_t>(), ctx->inc.as<uint32_t>(), ctx->conn.as<int32_t>(),
+                       ctx->iperm.as<int32_t>(), ctx->tile_deg.as<int32_t>(), ctx->tile_off.as<int64_t>(), N, B, T,
+                       ctx->ell.as<int2>(), s);
+    }
     HIPCHK(hipGetLastError());
     ctx->have_order = true;
     return MAG_OK;
@@ -314,7 +380,16 @@ magk::OpParams op_params(mag_ctx *ctx)
     P.maskP = ctx->maskP.as<uint8_t>();
     P.tile_deg = ctx->tile_deg.as<int32_t>();
     P.tile_off = ctx->tile_off.as<int64_t>();
-    P.ell = ctx->ell.as<int2>();
+    if (ctx->use_lds) {
+        P.ell16 = ctx->ell.as<uint32_t>();
+        P.tile_hoff = ctx->tile_hoff.as<int32_t>();
+        P.halo_g = ctx->halo_g.as<int32_t>();
+        P.cap = ctx->cap;
+    } else {
+        P.ell = ctx->ell.as<int2>();
+    }
+    P.wt = ctx->tune_wt;
+    if (const char *e = getenv("MAG_TUNE_ABLATE")) P.ablate = atoi(e);
     P.c0 = ctx->youngs * ctx->thick / (2.0 * (1.0 - ctx->nu * ctx->nu));
     P.nu = ctx->nu;
     P.h = (1.0 - ctx->nu) / 2.0;
@@ -372,6 +447,7 @@ void iteration_params(mag_ctx *ctx, int parity, magk::OpParams &P, magk::UpdPara
     U.partPQ = ctx->partPQ.as<double>();
     U.partRR = ctx->partRR.as<double>();
     U.st = ctx->state.as<CgState>();
+    U.wt = ctx->tune_wt;
 }
 
 // one block of G CG iterations on the stream (parity 0 first: p_prev = p1, p_new = p0)
@@ -393,7 +469,8 @@ int ensure_graph(mag_ctx *ctx, int G)
     mag_ctx::GraphKey k = {};
     void *ptrs[] = {ctx->x.p,  ctx->r.p,      ctx->p0.p,     ctx->p1.p,    ctx->q.p,        ctx->partRR.p,
                     ctx->partPQ.p, ctx->state.p, ctx->hist.p,   ctx->xyP.p,   ctx->maskP.p,    ctx->tile_deg.p,
-                    ctx->tile_off.p, ctx->ell.p};
+                    ctx->tile_off.p, ctx->ell.p, ctx->tile_hoff.p, ctx->halo_g.p,
+                    (void *)(intptr_t)(ctx->use_lds ? ctx->cap : -1)};
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) k.ptrs[i] = ptrs[i];
     k.N = ctx->N;
     k.T = ctx->T;
@@ -402,8 +479,8 @@ int ensure_graph(mag_ctx *ctx, int G)
     k.hist_len = ctx->opt.history_len;
     // material constants are baked into the kernel arguments too
     double mat[2] = {ctx->youngs * ctx->thick, ctx->nu};
-    memcpy(&k.ptrs[14], &mat[0], 8);
-    memcpy(&k.ptrs[15], &mat[1], 8);
+    memcpy(&k.ptrs[18], &mat[0], 8);
+    memcpy(&k.ptrs[19], &mat[1], 8);
     if (ctx->graph && memcmp(&k, &ctx->gkey, sizeof k) == 0) return MAG_OK;
     if (ctx->graph) {
         (void)hipGraphExecDestroy(ctx->graph);
@@ -501,6 +578,7 @@ void mag_default_options(mag_options *o)
     o->tile_nodes = 512;
     o->history_len = 0;
     o->verbose = 0;
+    o->op_variant = 0;
 }
 
 mag_ctx *mag_create(const mag_options *opt)
@@ -521,6 +599,7 @@ mag_ctx *mag_create(const mag_options *opt)
     if (!(o.tol >= 0.0)) o.tol = MAG_TARGET_CG_COST;
     ctx->B = o.tile_nodes;
     ctx->device = o.device;
+    if (const char *e = getenv("MAG_TUNE_WT")) ctx->tune_wt = atoi(e);
     hipError_t e = hipSetDevice(ctx->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     for (int i = 0; e == hipSuccess && i < 10; ++i) e = hipEventCreate(&ctx->ev[i]);
@@ -547,7 +626,8 @@ void mag_destroy(mag_ctx *ctx)
         DevBuf *bufs[] = {&ctx->xy, &ctx->conn, &ctx->uknown, &ctx->uin, &ctx->fin, &ctx->scratch, &ctx->small,
                           &ctx->sK0, &ctx->sK1, &ctx->sV0, &ctx->sV1, &ctx->perm, &ctx->iperm, &ctx->xyP,
                           &ctx->maskP, &ctx->deg, &ctx->inc_off, &ctx->inc, &ctx->tile_deg, &ctx->tile_cnt,
-                          &ctx->tile_off, &ctx->ell, &ctx->pk0, &ctx->pk1, &ctx->pv0, &ctx->pv1, &ctx->head,
+                          &ctx->tile_off, &ctx->ell, &ctx->hcnt, &ctx->hoffn, &ctx->hk0, &ctx->hk1, &ctx->halo_g,
+                          &ctx->tile_hcnt, &ctx->tile_hoff, &ctx->pk0, &ctx->pk1, &ctx->pv0, &ctx->pv1, &ctx->head,
                           &ctx->blk, &ctx->rowcnt, &ctx->seg_start, &ctx->bptr, &ctx->bcol, &ctx->kval, &ctx->ke,
                           &ctx->isfree, &ctx->fidx, &ctx->rcnt, &ctx->rowoff, &ctx->rp_ff, &ctx->col_ff,
                           &ctx->val_ff, &ctx->b_ff, &ctx->rp_full, &ctx->col_full, &ctx->x, &ctx->r, &ctx->p0,
@@ -694,6 +774,9 @@ int mag_run(mag_ctx *ctx)
     st.nnz = csr ? 4 * ctx->nb : 0;
     st.num_tiles = ctx->T;
     st.ell_entries = ctx->ell_total;
+    st.halo_nodes = ctx->halo_total;
+    st.max_tile_halo = ctx->max_halo;
+    st.lds_operator = ctx->use_lds ? 1 : 0;
     // n_free is only needed for reporting; count on the host side of the mask would cost a pass, so
     // take it from the mask on the device lazily in mag_reduce_system; here report -1 if unknown.
     st.n_free = -1;
@@ -871,9 +954,16 @@ int mag_time_operator(mag_ctx *ctx, int32_t reps, double *ms_per_launch)
     magk::UpdParams U;
     iteration_params(ctx, 0, P, U);
     P.hist_len = 0;
+    const char *what = getenv("MAG_TUNE_TIMEWHAT");
+    const int tw = what ? atoi(what) : 0;
     for (int i = 0; i < 3; ++i) magk::op_launch(P, ctx->B, true, s);
     HIPCHK(hipEventRecord(ctx->ev[8], s));
-    for (int i = 0; i < reps; ++i) magk::op_launch(P, ctx->B, true, s);
+    for (int i = 0; i < reps; ++i) {
+        if (tw == 1)
+            magk::upd_launch(U, ctx->B, s);
+        else
+            magk::op_launch(P, ctx->B, true, s);
+    }
     HIPCHK(hipEventRecord(ctx->ev[9], s));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));

@@ -31,6 +31,23 @@ namespace magk {
 
 int cg_grid(int32_t T) { return T < kMaxGrid ? (T < 1 ? 1 : T) : kMaxGrid; }
 
+// 16-byte store, optionally write-through (sc1): a launch that leaves its output dirty in the XCD L2s pays
+// the write-back at the kernel boundary (MI355X_MICROARCH.md, price-list row "boundary": + B / 6 TB/s), on the
+// critical path of the next launch; write-through moves it under the launch's own streaming.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+template <bool WT>
+__device__ inline void store2(double2 *base, int64_t n_nodes, int64_t idx, double2 v)
+{
+    if (WT) {
+        auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, (short)0, (int)(n_nodes * 16), 0x00020000);
+        u32x4 d;
+        __builtin_memcpy(&d, &v, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, (int)(idx * 16), 0, 16);
+    } else {
+        base[idx] = v;
+    }
+}
+
 // ------------------------------------------------------------ reductions ---
 template <int B>
 __device__ inline double block_sum(double v, double *s_red)
@@ -219,9 +236,220 @@ __global__ void __launch_bounds__(B) k_operator(const OpParams P)
     }
 }
 
+// ----------------------------------------- operator kernel, LDS halo ---
+// Same operator on the tile-local table (fill_ell16): the tile's halo nodes are staged in LDS next to
+// its owned nodes, so the incident-element loop is LDS + ALU only and every global access of the launch
+// is issued up front.  Slot words of the first 8 incident elements are prefetched into registers.
+constexpr int kSlotRegs = 8;
+
+template <int B, bool CG, bool WT>
+__global__ void __launch_bounds__(B) k_operator_lds(const OpParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 smem[];
+    double2 *s_xy = smem;
+    double2 *s_p = smem + P.cap;
+    double *s_red = (double *)(smem + 2 * P.cap);
+
+    const int tid = threadIdx.x;
+    // registers of the tile in flight
+    int64_t node = 0;
+    bool valid = false, hvalid = false;
+    double2 ca, a0, a1, hc, h0, h1;
+    uint8_t m = 3, hm = 0;
+    int32_t deg = 0, nh = 0, hoff = 0;
+    uint32_t w[kSlotRegs];
+    const uint32_t *ell = nullptr;
+
+    auto load_tile = [&](int32_t t) {
+        node = (int64_t)t * B + tid;
+        valid = node < P.N;
+        ca = a0 = a1 = make_double2(0.0, 0.0);
+        m = 3;
+        if (valid) {
+            ca = P.xyP[node];
+            m = P.maskP[node];
+            if (CG) {
+                a0 = P.r[node];
+                a1 = P.pprev[node];
+            } else {
+                a0 = P.v[node];
+            }
+        }
+        deg = P.tile_deg[t];
+        ell = P.ell16 + P.tile_off[t] + tid;
+#pragma unroll
+        for (int k = 0; k < kSlotRegs; ++k) w[k] = k < deg ? ell[(int64_t)k * B] : 0xffffffffu;
+        hoff = P.tile_hoff[t];
+        nh = P.tile_hoff[t + 1] - hoff;
+        hvalid = tid < nh && !(P.ablate & 4);
+        hc = h0 = h1 = make_double2(0.0, 0.0);
+        hm = 0;
+        if (hvalid) {
+            const int32_t g = P.halo_g[hoff + tid];
+            hc = P.xyP[g];
+            if (CG) {
+                h0 = P.r[g];
+                h1 = P.pprev[g];
+            } else {
+                h0 = P.v[g];
+                hm = P.maskP[g];
+            }
+        }
+    };
+
+    load_tile(blockIdx.x);
+
+    double beta = 0.0;
+    if (CG) {
+        CgState *st = P.st;
+        const long long k = st->iterA;
+        const int was_done = st->done;
+        const double rr = sum_partials<B>(P.partRR, P.nPart, s_red);
+        if (was_done) return;
+        const double cost = st->stop_mode == 1 ? fabs(rr) : sqrt(rr);
+        const bool finished = (k >= 1) && (cost <= st->target);
+        const bool broke = !(fabs(rr) <= 1.79769313486231570e308);
+        const bool maxed = k >= st->max_iter;
+        if (blockIdx.x == 0 && tid == 0) {
+            if (k >= 1 && k - 1 < P.hist_len) P.hist[k - 1] = cost;
+            if (finished || broke || maxed) {
+                st->iterations = k;
+                st->final_cost = cost;
+                st->converged = finished ? 1 : 0;
+                st->breakdown = broke ? 1 : 0;
+                st->done = 1;
+            } else {
+                st->rr_hist[k & 1] = rr;
+                st->iterB = k;
+            }
+        }
+        if (finished || broke || maxed) return;
+        const double rr_prev = (k == 0) ? rr : st->rr_hist[(k + 1) & 1];
+        beta = rr / rr_prev;
+    }
+
+    const double c0 = P.c0, nu = P.nu, h = P.h;
+    double acc = 0.0;
+    int32_t t = blockIdx.x;
+    for (;;) {
+        double2 pa;
+        if (CG) {
+            pa.x = -a0.x + beta * a1.x;
+            pa.y = -a0.y + beta * a1.y;
+            if (valid && (!(P.ablate & 2) || pa.x == 1.2345e300)) store2<WT>(P.pnew, P.N, node, pa);
+        } else {
+            pa = a0;
+            if (P.masked) {
+                if (m & 1) pa.x = 0.0;
+                if (m & 2) pa.y = 0.0;
+            }
+        }
+        __syncthreads(); // previous tile's readers are done with the LDS images
+        s_xy[tid] = ca;
+        s_p[tid] = pa;
+        if (hvalid) {
+            double2 hp;
+            if (CG) {
+                hp.x = -h0.x + beta * h1.x;
+                hp.y = -h0.y + beta * h1.y;
+            } else {
+                hp = h0;
+                if (P.masked) {
+                    if (hm & 1) hp.x = 0.0;
+                    if (hm & 2) hp.y = 0.0;
+                }
+            }
+            s_xy[B + tid] = hc;
+            s_p[B + tid] = hp;
+        }
+        for (int32_t hh = tid + B; hh < nh; hh += B) { // tiles with more halo nodes than threads (rare)
+            const int32_t g = P.halo_g[hoff + hh];
+            double2 hp;
+            if (CG) {
+                const double2 r2 = P.r[g], pp = P.pprev[g];
+                hp.x = -r2.x + beta * pp.x;
+                hp.y = -r2.y + beta * pp.y;
+            } else {
+                hp = P.v[g];
+                if (P.masked) {
+                    const uint8_t mm = P.maskP[g];
+                    if (mm & 1) hp.x = 0.0;
+                    if (mm & 2) hp.y = 0.0;
+                }
+            }
+            s_xy[B + hh] = P.xyP[g];
+            s_p[B + hh] = hp;
+        }
+        __syncthreads();
+
+        double fx = 0.0, fy = 0.0;
+        if (P.ablate & 1) { // tuning only: no incident-element loop
+            fx = s_p[(tid + 1) & (B - 1)].x;
+            fy = s_xy[(tid + 1) & (B - 1)].y;
+#pragma unroll
+            for (int k = 0; k < kSlotRegs; ++k) fx += (double)(w[k] & 1u);
+        } else
+#pragma unroll
+        for (int k = 0; k < kSlotRegs; ++k) {
+            const uint32_t ww = w[k];
+            if (ww != 0xffffffffu) {
+                const uint32_t lb = ww & 0xffffu, lc = ww >> 16;
+                corner_force(ca, pa, s_xy[lb], s_p[lb], s_xy[lc], s_p[lc], c0, nu, h, fx, fy);
+            }
+        }
+        for (int32_t k = kSlotRegs; k < deg; ++k) {
+            const uint32_t ww = ell[(int64_t)k * B];
+            if (ww != 0xffffffffu) {
+                const uint32_t lb = ww & 0xffffu, lc = ww >> 16;
+                corner_force(ca, pa, s_xy[lb], s_p[lb], s_xy[lc], s_p[lc], c0, nu, h, fx, fy);
+            }
+        }
+        if (valid) {
+            if (CG || P.masked) {
+                if (m & 1) fx = 0.0;
+                if (m & 2) fy = 0.0;
+            }
+            if (CG) {
+                if (!(P.ablate & 2) || fx == 1.2345e300) store2<WT>(P.q, P.N, node, make_double2(fx, fy));
+                acc += pa.x * fx + pa.y * fy;
+            } else {
+                P.y[node] = make_double2(fx, fy);
+            }
+        }
+        t += gridDim.x;
+        if (t >= P.T) break;
+        load_tile(t);
+    }
+    if (CG) {
+        const double tot = block_sum<B>(acc, s_red);
+        if (tid == 0) P.partPQ[blockIdx.x] = tot;
+    }
+}
+
+size_t op_lds_bytes(int32_t cap, int32_t B) { return (size_t)cap * 32 + (size_t)(B / 64) * 8 + 16; }
+
 void op_launch(const OpParams &P, int32_t B, bool cg_mode, hipStream_t s)
 {
     const int grid = cg_grid(P.T);
+    if (P.ell16) {
+        const size_t lds = op_lds_bytes(P.cap, B);
+#define MAG_OPL(BB)                                                       \
+    if (!cg_mode)                                                         \
+        k_operator_lds<BB, false, false><<<grid, BB, lds, s>>>(P);        \
+    else if (P.wt)                                                        \
+        k_operator_lds<BB, true, true><<<grid, BB, lds, s>>>(P);          \
+    else                                                                  \
+        k_operator_lds<BB, true, false><<<grid, BB, lds, s>>>(P);
+        if (B == 256) {
+            MAG_OPL(256)
+        } else if (B == 1024) {
+            MAG_OPL(1024)
+        } else {
+            MAG_OPL(512)
+        }
+#undef MAG_OPL
+        return;
+    }
 #define MAG_OP(BB)                                                     \
     if (cg_mode)                                                       \
         k_operator<BB, true><<<grid, BB, 0, s>>>(P);                   \
@@ -239,29 +467,45 @@ void op_launch(const OpParams &P, int32_t B, bool cg_mode, hipStream_t s)
 
 // -------------------------------------------------------- update kernel ---
 // alpha = rtr/(p.q); x += alpha p; r += alpha q; partial r.r   (argmin next_iter)
-template <int B>
+template <int B, bool WT>
 __global__ void __launch_bounds__(B) k_update(const UpdParams P)
 {
     __shared__ double s_red[B / 64];
     CgState *st = P.st;
     const int done = st->done;
     const long long k = st->iterB;
+    // first tile's operands are in flight while the p.q partials are reduced
+    int32_t t = blockIdx.x;
+    int64_t node = (int64_t)t * B + threadIdx.x;
+    double2 p = make_double2(0.0, 0.0), q = p, x = p, r = p;
+    if (node < P.N) {
+        p = P.p[node];
+        q = P.q[node];
+        x = P.x[node];
+        r = P.r[node];
+    }
     const double pq = sum_partials<B>(P.partPQ, P.nPart, s_red);
     if (done) return;
     const double alpha = st->rr_hist[k & 1] / pq;
     double acc = 0.0;
-    for (int32_t t = blockIdx.x; t < P.T; t += gridDim.x) {
-        const int64_t node = (int64_t)t * B + threadIdx.x;
+    for (;;) {
         if (node < P.N) {
-            const double2 p = P.p[node], q = P.q[node];
-            double2 x = P.x[node], r = P.r[node];
             x.x += alpha * p.x;
             x.y += alpha * p.y;
             r.x += alpha * q.x;
             r.y += alpha * q.y;
-            P.x[node] = x;
-            P.r[node] = r;
+            store2<WT>(P.x, P.N, node, x);
+            store2<WT>(P.r, P.N, node, r);
             acc += r.x * r.x + r.y * r.y;
+        }
+        t += gridDim.x;
+        if (t >= P.T) break;
+        node = (int64_t)t * B + threadIdx.x;
+        if (node < P.N) {
+            p = P.p[node];
+            q = P.q[node];
+            x = P.x[node];
+            r = P.r[node];
         }
     }
     const double tot = block_sum<B>(acc, s_red);
@@ -277,12 +521,19 @@ __global__ void __launch_bounds__(B) k_update(const UpdParams P)
 void upd_launch(const UpdParams &P, int32_t B, hipStream_t s)
 {
     const int grid = cg_grid(P.T);
-    if (B == 256)
-        k_update<256><<<grid, 256, 0, s>>>(P);
-    else if (B == 1024)
-        k_update<1024><<<grid, 1024, 0, s>>>(P);
-    else
-        k_update<512><<<grid, 512, 0, s>>>(P);
+#define MAG_UPD(BB)                                  \
+    if (P.wt)                                        \
+        k_update<BB, true><<<grid, BB, 0, s>>>(P);   \
+    else                                             \
+        k_update<BB, false><<<grid, BB, 0, s>>>(P);
+    if (B == 256) {
+        MAG_UPD(256)
+    } else if (B == 1024) {
+        MAG_UPD(1024)
+    } else {
+        MAG_UPD(512)
+    }
+#undef MAG_UPD
 }
 
 // ------------------------------------------------------------ init/setup ---

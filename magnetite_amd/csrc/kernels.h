@@ -11,6 +11,7 @@ namespace magk {
 
 constexpr int kMaxGrid = 1024;  // cap on workgroups of the CG kernels == number of dot partials
 constexpr int kHilbertBits = 16;
+constexpr int kMaxLdsNodes = 2016; // (owned + halo) nodes per tile the LDS-halo operator stages: 32 B each < 64 KiB
 
 // ------------------------------------------------------------ symbolic.hip
 // bbox[4] = {xmin, ymin, xmax, ymax}; scratch >= 4*256 doubles
@@ -31,6 +32,20 @@ void tile_degree(const int32_t *deg, int64_t N, int32_t B, int32_t T, int32_t *t
 void fill_ell(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn, const int32_t *iperm,
               const int32_t *tile_deg, const int64_t *tile_off, int64_t N, int32_t B, int32_t T, int2 *ell,
               hipStream_t s);
+// tile-local numbering: per node count of references to nodes of other tiles (cnt[N] = 0 sentinel) ...
+void halo_count(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn, const int32_t *iperm, int64_t N,
+                int32_t B, int32_t *cnt, hipStream_t s);
+// ... their keys (tile<<32 | node) at off[i]..., to be sorted and uniqued ...
+void halo_emit(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn, const int32_t *iperm, int64_t N,
+               int32_t B, const int32_t *off, uint64_t *keys, hipStream_t s);
+// ... halo_g[blk] = node of each unique key, tile_hcnt[tile]++ ...
+void halo_unique(const uint64_t *keys, const int32_t *head, const int32_t *blk, int64_t n, int32_t *halo_g,
+                 int32_t *tile_hcnt, hipStream_t s);
+// ... and the ELL table with 16-bit tile-local ids: word = lb | lc<<16, 0xffffffff pads; owned l < B,
+// halo B + rank in halo_g[tile_hoff[t]..tile_hoff[t+1])
+void fill_ell16(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn, const int32_t *iperm,
+                const int32_t *tile_deg, const int64_t *tile_off, const int32_t *tile_hoff, const int32_t *halo_g,
+                int64_t N, int32_t B, int32_t T, uint32_t *ell, hipStream_t s);
 // CSR pattern: 9 (row node, col node) pairs per element, key = row<<32 | col, val = 9e + 3a + b
 void csr_pairs(const int32_t *conn, int64_t E, uint64_t *keys, uint32_t *vals, hipStream_t s);
 // head[k] = 1 where sorted key k starts a new (row,col) block
@@ -105,7 +120,13 @@ struct OpParams {
     const uint8_t *maskP;
     const int32_t *tile_deg;
     const int64_t *tile_off;
-    const int2 *ell;
+    const int2 *ell;         // gather variant: global (Hilbert) ids, halo read from global memory
+    const uint32_t *ell16;   // LDS-halo variant (nullptr => gather variant): tile-local ids lb | lc<<16
+    const int32_t *tile_hoff; // T+1 offsets into halo_g
+    const int32_t *halo_g;   // per tile: sorted Hilbert ids of its halo nodes
+    int32_t cap;             // LDS image capacity in nodes: B + max halo, <= kMaxLdsNodes
+    int32_t wt;              // write-through (sc1) stores of pnew and q
+    int32_t ablate;          // tuning only: 1 skip element loop, 2 skip stores, 4 skip halo loads
     double c0, nu, h; // E t / (2 (1-nu^2)), nu, (1-nu)/2
     // CG mode
     const double2 *r;
@@ -134,6 +155,7 @@ struct UpdParams {
     const double *partPQ;
     double *partRR;
     CgState *st;
+    int32_t wt;
 };
 
 int cg_grid(int32_t T);

@@ -30,6 +30,12 @@ hipError_t sort_pairs_u64(void *tmp, size_t *tmp_bytes, const uint64_t *kin, uin
                                      (unsigned)end_bit, s);
 }
 
+hipError_t sort_keys_u64(void *tmp, size_t *tmp_bytes, const uint64_t *kin, uint64_t *kout, size_t n, int begin_bit,
+                         int end_bit, hipStream_t s)
+{
+    return rocprim::radix_sort_keys(tmp, *tmp_bytes, kin, kout, n, (unsigned)begin_bit, (unsigned)end_bit, s);
+}
+
 hipError_t exclusive_scan_i32(void *tmp, size_t *tmp_bytes, const int32_t *in, int32_t *out, size_t n,
                               hipStream_t s)
 {

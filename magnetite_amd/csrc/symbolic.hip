@@ -227,6 +227,123 @@ void fill_ell(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn, 
     k_fill_ell<<<T, 256, 0, s>>>(inc_off, inc, conn, iperm, tile_deg, tile_off, N, B, ell);
 }
 
+// ------------------------------------------ tile-local numbering (halo) ---
+// A tile's halo = distinct nodes referenced by its nodes' incident elements but owned by another tile.
+// count / emit (tile<<32 | node) refs per node, sort + unique (host side drives rocPRIM), then the ELL
+// table is rewritten with 16-bit tile-local ids: owned l in [0,B), halo B + rank in the tile's sorted list.
+template <bool EMIT>
+__global__ void __launch_bounds__(256) k_halo_refs(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn,
+                                                   const int32_t *iperm, int64_t N, int32_t B, int32_t *cnt,
+                                                   const int32_t *off, uint64_t *keys)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i > N) return;
+    int32_t c = 0;
+    if (i < N) {
+        const int32_t t = (int32_t)(i / B);
+        const int32_t o = inc_off[i], d = inc_off[i + 1] - o;
+        int64_t w = EMIT ? off[i] : 0;
+        for (int k = 0; k < d; ++k) {
+            const uint32_t v = inc[o + k];
+            const uint32_t e = v / 3u, cc = v - 3u * e;
+            const uint32_t c1 = cc == 2 ? 0 : cc + 1, c2 = c1 == 2 ? 0 : c1 + 1;
+            const int32_t g1 = iperm[conn[3 * (int64_t)e + c1]], g2 = iperm[conn[3 * (int64_t)e + c2]];
+            if (g1 / B != t) {
+                if (EMIT) keys[w++] = ((uint64_t)(uint32_t)t << 32) | (uint32_t)g1;
+                ++c;
+            }
+            if (g2 / B != t) {
+                if (EMIT) keys[w++] = ((uint64_t)(uint32_t)t << 32) | (uint32_t)g2;
+                ++c;
+            }
+        }
+    }
+    if (!EMIT) cnt[i] = c; // entry N is the scan's sentinel
+}
+
+void halo_count(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn, const int32_t *iperm, int64_t N,
+                int32_t B, int32_t *cnt, hipStream_t s)
+{
+    k_halo_refs<false><<<blocks_for(N + 1, 256), 256, 0, s>>>(inc_off, inc, conn, iperm, N, B, cnt, nullptr, nullptr);
+}
+
+void halo_emit(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn, const int32_t *iperm, int64_t N,
+               int32_t B, const int32_t *off, uint64_t *keys, hipStream_t s)
+{
+    k_halo_refs<true><<<blocks_for(N + 1, 256), 256, 0, s>>>(inc_off, inc, conn, iperm, N, B, nullptr, off, keys);
+}
+
+__global__ void __launch_bounds__(256) k_halo_unique(const uint64_t *keys, const int32_t *head, const int32_t *blk,
+                                                     int64_t n, int32_t *halo_g, int32_t *tile_hcnt)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n || !head[k]) return;
+    const uint64_t key = keys[k];
+    halo_g[blk[k]] = (int32_t)(key & 0xffffffffu);
+    atomicAdd(&tile_hcnt[(int32_t)(key >> 32)], 1);
+}
+
+void halo_unique(const uint64_t *keys, const int32_t *head, const int32_t *blk, int64_t n, int32_t *halo_g,
+                 int32_t *tile_hcnt, hipStream_t s)
+{
+    k_halo_unique<<<blocks_for(n, 256), 256, 0, s>>>(keys, head, blk, n, halo_g, tile_hcnt);
+}
+
+__device__ inline uint32_t local_id(int32_t g, int32_t base, int32_t B, const int32_t *hl, int32_t nh)
+{
+    const uint32_t l = (uint32_t)(g - base);
+    if (l < (uint32_t)B) return l;
+    int32_t lo = 0, hi = nh - 1;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (hl[mid] < g)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return (uint32_t)(B + lo);
+}
+
+__global__ void __launch_bounds__(256) k_fill_ell16(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn,
+                                                    const int32_t *iperm, const int32_t *tile_deg,
+                                                    const int64_t *tile_off, const int32_t *tile_hoff,
+                                                    const int32_t *halo_g, int64_t N, int32_t B, uint32_t *ell)
+{
+    const int32_t t = blockIdx.x;
+    const int32_t td = tile_deg[t];
+    const int32_t base = t * B;
+    const int32_t *hl = halo_g + tile_hoff[t];
+    const int32_t nh = tile_hoff[t + 1] - tile_hoff[t];
+    uint32_t *dst = ell + tile_off[t];
+    for (int l = threadIdx.x; l < B; l += 256) {
+        const int64_t i = (int64_t)base + l;
+        int32_t o = 0, d = 0;
+        if (i < N) {
+            o = inc_off[i];
+            d = inc_off[i + 1] - o;
+        }
+        for (int k = 0; k < td; ++k) {
+            uint32_t w = 0xffffffffu;
+            if (k < d) {
+                const uint32_t v = inc[o + k];
+                const uint32_t e = v / 3u, c = v - 3u * e;
+                const uint32_t c1 = c == 2 ? 0 : c + 1, c2 = c1 == 2 ? 0 : c1 + 1;
+                const uint32_t lb = local_id(iperm[conn[3 * (int64_t)e + c1]], base, B, hl, nh);
+                const uint32_t lc = local_id(iperm[conn[3 * (int64_t)e + c2]], base, B, hl, nh);
+                w = lb | (lc << 16);
+            }
+            dst[(int64_t)k * B + l] = w;
+        }
+    }
+}
+
+void fill_ell16(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn, const int32_t *iperm,
+                const int32_t *tile_deg, const int64_t *tile_off, const int32_t *tile_hoff, const int32_t *halo_g,
+                int64_t N, int32_t B, int32_t T, uint32_t *ell, hipStream_t s)
+{
+    k_fill_ell16<<<T, 256, 0, s>>>(inc_off, inc, conn, iperm, tile_deg, tile_off, tile_hoff, halo_g, N, B, ell);
+}
+
 // --------------------------------------------------------- CSR pattern ---
 __global__ void __launch_bounds__(256) k_csr_pairs(const int32_t *conn, int64_t n9, uint64_t *keys, uint32_t *vals)
 {
