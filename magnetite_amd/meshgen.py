@@ -251,3 +251,64 @@ def baseline_problem(which, scale=1.0):
         n = grid_for_triangles(16e6 * scale * scale, np.pi * 0.25 ** 2)
         return config_fixed_left_pull_right(multi_hole(n, 4, 0.25))
     raise KeyError(which)
+
+
+def check_ccw(mesh):
+    """mesher.rs:522-526 as written: an element whose SIGNED area is < 1.0 gets its node list reversed.
+    (Looks like a typo for < 0.0; on a fine mesh every CCW element has area < 1 and ends up clockwise.)"""
+    a = mesh.xy[mesh.conn]
+    area = 0.5 * (a[:, 0, 0] * (a[:, 1, 1] - a[:, 2, 1]) + a[:, 1, 0] * (a[:, 2, 1] - a[:, 0, 1]) +
+                  a[:, 2, 0] * (a[:, 0, 1] - a[:, 1, 1]))
+    conn = mesh.conn.copy()
+    flip = area < 1.0
+    conn[flip] = conn[flip][:, ::-1]
+    return Mesh(mesh.xy.copy(), np.ascontiguousarray(conn), mesh.name + "_checkccw")
+
+
+def _inside(poly, pts):
+    """Even-odd ray casting, vectorised: poly (M,2) closed implicitly, pts (K,2)."""
+    x, y = pts[:, 0][:, None], pts[:, 1][:, None]
+    x0, y0 = poly[:, 0][None, :], poly[:, 1][None, :]
+    x1, y1 = np.roll(poly[:, 0], -1)[None, :], np.roll(poly[:, 1], -1)[None, :]
+    cond = (y0 > y) != (y1 > y)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        xint = x0 + (y - y0) * (x1 - x0) / (y1 - y0)
+    return (np.sum(cond & (x < xint), axis=1) % 2) == 1
+
+
+def polygon_mesh(outline, h, name="polygon"):
+    """Unstructured CCW triangulation of a simple polygon (stand-in for `gmsh geom.geo -2`, mesher.rs:501-506):
+    boundary points every <= h along the outline + a staggered interior lattice, Delaunay, triangles whose
+    centroid is outside the polygon dropped.  Deterministic."""
+    from scipy.spatial import Delaunay
+    outline = np.asarray(outline, dtype=np.float64)
+    bpts = []
+    for a, b in zip(outline, np.roll(outline, -1, axis=0)):
+        n = max(1, int(np.ceil(np.linalg.norm(b - a) / h)))
+        for k in range(n):
+            bpts.append(a + (b - a) * (k / n))
+    bpts = np.array(bpts)
+    lo, hi = outline.min(axis=0), outline.max(axis=0)
+    ys = np.arange(lo[1] + 0.5 * h, hi[1], h * np.sqrt(3) / 2)
+    ipts = []
+    for j, yv in enumerate(ys):
+        xs = np.arange(lo[0] + (0.5 if j % 2 else 0.25) * h, hi[0], h)
+        ipts.append(np.stack([xs, np.full_like(xs, yv)], axis=1))
+    ipts = np.concatenate(ipts)
+    ipts = ipts[_inside(outline, ipts)]
+    # keep interior points at least 0.5 h away from every boundary point
+    d2 = ((ipts[:, None, :] - bpts[None, :, :]) ** 2).sum(axis=2).min(axis=1)
+    ipts = ipts[d2 > (0.5 * h) ** 2]
+    pts = np.concatenate([bpts, ipts])
+    tri = Delaunay(pts).simplices.astype(np.int64)
+    cen = pts[tri].mean(axis=1)
+    tri = tri[_inside(outline, cen)]
+    a = pts[tri]
+    area = 0.5 * ((a[:, 1, 0] - a[:, 0, 0]) * (a[:, 2, 1] - a[:, 0, 1]) - (a[:, 2, 0] - a[:, 0, 0]) * (a[:, 1, 1] - a[:, 0, 1]))
+    tri = tri[np.abs(area) > 1e-9 * h * h]
+    area = area[np.abs(area) > 1e-9 * h * h]
+    tri[area < 0] = tri[area < 0][:, ::-1]
+    used = np.zeros(len(pts), dtype=bool)
+    used[tri.reshape(-1)] = True
+    remap = np.cumsum(used) - 1
+    return Mesh(np.ascontiguousarray(pts[used]), remap[tri].astype(np.int32), name)

@@ -194,3 +194,93 @@ def test_reference_interface_run(built):
     nodes[0].fx = 1.0  # both known on one DOF: the reference panics (solver.rs:431); here a Solver error
     with pytest.raises(MagnetiteError):
         run(nodes, elements, ModelMetadata(p.youngs_modulus, p.poisson_ratio, p.part_thickness))
+
+
+@pytest.mark.parametrize("name", ["tensile", "plate"])
+def test_against_committed_golden_fixtures(built, name):
+    """tests/golden/*.npz (oracle outputs, generated by tests/golden/make_fixtures.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    E, nu, t = g["material"]
+    with Context(device=0, history_len=32) as c:
+        c.upload(g["xy"].reshape(-1), g["conn"].reshape(-1), g["u_known"], g["u_in"], g["f_in"], E, nu, t)
+        if "ke" in g:
+            assert np.array_equal(c.element_stiffness(), g["ke"])
+            rowptr, col, val = c.assemble_csr()
+            assert np.array_equal(rowptr, g["K_rowptr"]) and np.array_equal(col, g["K_col"])
+            assert np.array_equal(val, g["K_val"])
+            rp, cl, vl, b = c.reduce_system()
+            assert np.array_equal(rp, g["A_rowptr"]) and np.array_equal(cl, g["A_col"])
+            assert np.array_equal(vl, g["A_val"]) and np.array_equal(b, g["b"])
+        c.run()
+        u, f, s = c.download()
+        st = c.stats()
+        hist = c.history(8)
+    assert rel(u, g["u"]) <= TOL_U
+    assert np.allclose(hist, g["history"][:8], rtol=1e-9)
+    assert abs(st["iterations"] - int(g["iterations"])) <= max(3, int(g["iterations"]) // 50)
+    stable = np.abs(g["stress"]) > 1e-3 * np.abs(g["stress"]).max()
+    assert np.allclose(s[stable], g["stress"][stable], rtol=1e-6)
+
+
+def test_gather_fallback_operator(built):
+    """op_variant=1 forces the global-gather operator (used when a tile's halo does not fit LDS)."""
+    p = PROBLEMS["hole_perturbed"]
+    ref = oracle_run(p)
+    with Context(device=0, op_variant=1) as c:
+        out = c.solve(p)
+    assert out["lds_operator"] == 0 and rel(out["u"], ref["u"]) <= TOL_U
+    with Context(device=0) as c:
+        out2 = c.solve(p)
+    assert out2["lds_operator"] == 1 and rel(out2["u"], out["u"]) <= 1e-10
+
+
+def test_high_valence_fan_mesh(built):
+    """A node shared by 40 elements: more incident elements than the slot words kept in registers."""
+    n = 40
+    ang = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    xy = np.concatenate([[[0.0, 0.0]], np.stack([np.cos(ang), np.sin(ang)], axis=1),
+                         1.8 * np.stack([np.cos(ang), np.sin(ang)], axis=1)])
+    tri = [[0, 1 + k, 1 + (k + 1) % n] for k in range(n)]
+    tri += [[1 + k, 1 + n + k, 1 + n + (k + 1) % n] for k in range(n)]
+    tri += [[1 + k, 1 + n + (k + 1) % n, 1 + (k + 1) % n] for k in range(n)]
+    m = meshgen.Mesh(xy, np.array(tri, dtype=np.int32), "fan")
+    p = meshgen.apply_boundary_rules(m, [meshgen.BoundaryRule("hold", x_max=-1.2, ux=0.0, uy=0.0),
+                                         meshgen.BoundaryRule("pull", x_min=1.2, ux=0.01, fy=0.0)])
+    ref = oracle_run(p)
+    for variant in (0, 1):
+        with Context(device=0, op_variant=variant, tile_nodes=256) as c:
+            out = c.solve(p)
+        assert rel(out["u"], ref["u"]) <= TOL_U
+
+
+@pytest.mark.parametrize("which,scale", [("hole1m", 1.0), ("plate100k", 1.0)])
+def test_full_size_properties(built, which, scale):
+    """BASELINE-size meshes, where the oracle does not finish in seconds: size-independent properties.
+    (1) K is symmetric: x.(Ky) == y.(Kx); (2) rigid translations are in the null space of the unmasked K;
+    (3) the returned u satisfies K_ff u_f = b to round-off, checked with the operator itself;
+    (4) the solve is linear in the load: solve(2 delta) == 2 solve(delta)."""
+    p = meshgen.baseline_problem(which, scale)
+    n = 2 * p.mesh.num_nodes
+    rng = np.random.default_rng(2024)
+    with Context(device=0, stop_mode=MAG_STOP_REL, tol=1e-10) as c:
+        c.upload_problem(p)
+        x, y = rng.standard_normal(n), rng.standard_normal(n)
+        Kx, Ky = c.apply_operator(x), c.apply_operator(y)
+        assert abs(x @ Ky - y @ Kx) <= 1e-11 * np.linalg.norm(x) * np.linalg.norm(Ky)
+        tx = np.tile([1.0, 0.0], n // 2)
+        ty = np.tile([0.0, 1.0], n // 2)
+        scale_k = np.abs(Kx).max() / np.abs(x).max()
+        assert np.abs(c.apply_operator(tx)).max() <= 1e-9 * scale_k
+        assert np.abs(c.apply_operator(ty)).max() <= 1e-9 * scale_k
+        out = c.solve(p)
+        assert out["converged"] == 1
+        free = p.u_known == 0
+        res = c.apply_operator(out["u"])          # K u (unmasked): on free rows must equal f_in
+        r = (res - p.f_in)[free]
+        fs = np.abs(c.apply_operator(np.where(free, 0.0, out["u"]))).max()  # scale of K_fk u_k
+        assert np.linalg.norm(r) <= 1e-8 * max(fs, np.abs(p.f_in).max()) * np.sqrt(free.sum())
+        p2 = meshgen.Problem(p.mesh, p.u_known, 2.0 * p.u_in, 2.0 * p.f_in, p.youngs_modulus, p.poisson_ratio,
+                             p.part_thickness)
+        out2 = c.solve(p2)
+        assert rel(out2["u"], 2.0 * out["u"]) <= 1e-8

@@ -1,0 +1,153 @@
+"""CPU: the oracle's two paths against each other, against an independent numpy twin, against an analytic
+patch test and against the committed golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+
+import numpy_twin as twin
+import oracle
+from magnetite_amd import meshgen
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def run(p, path, **kw):
+    return oracle.run(p.xy_flat, p.conn_flat, p.u_known, p.u_in, p.f_in, p.youngs_modulus, p.poisson_ratio,
+                      p.part_thickness, path=path, **kw)
+
+
+def rel(a, b):
+    return np.linalg.norm(a - b) / np.linalg.norm(b)
+
+
+CASES = {
+    "plate": lambda: meshgen.config_fixed_left_pull_right(meshgen.plate(7, 5, 1.4, 1.0)),
+    "shuffled_load": lambda: meshgen.config_fixed_left_point_load(meshgen.shuffle(meshgen.plate(9), 1)),
+    "hole_perturbed": lambda: meshgen.config_fixed_left_pull_right(
+        meshgen.shuffle(meshgen.perturb(meshgen.plate_with_holes(14), 0.2), 2)),
+    "clockwise": lambda: meshgen.config_fixed_left_pull_right(meshgen.clockwise(meshgen.plate(8))),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_dense_and_sparse_paths_are_bit_identical(built, name):
+    """The sparse restatement must reproduce the reference-faithful O(n^2) path exactly: same K_e, same '+=' order."""
+    p = CASES[name]()
+    a, b = run(p, "dense", hist_len=50), run(p, "sparse", hist_len=50)
+    for k in ("u", "f", "stress", "history"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["iterations"] == b["iterations"] and a["nnz_ff"] == b["nnz_ff"] and a["n_free"] == b["n_free"]
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_matches_numpy_twin(built, name):
+    p = CASES[name]()
+    t = twin.solve(p.mesh.xy, p.mesh.conn, p.u_known, p.u_in, p.f_in, p.youngs_modulus, p.poisson_ratio,
+                   p.part_thickness)
+    # element matrices and assembled K: same formulas, different summation order
+    ke = oracle.element_stiffness_all(p.xy_flat, p.conn_flat, p.poisson_ratio, p.youngs_modulus, p.part_thickness)
+    for e in (0, len(ke) // 2, len(ke) - 1):
+        want = twin.element_stiffness(p.mesh.xy, p.mesh.conn[e], p.poisson_ratio, p.youngs_modulus, p.part_thickness)
+        assert np.abs(ke[e] - want).max() <= 1e-13 * np.abs(want).max()
+    K = oracle.assemble_sparse(p.xy_flat, p.conn_flat, p.poisson_ratio, p.youngs_modulus, p.part_thickness)
+    assert np.abs(K.toarray() - t["K"]).max() <= 1e-13 * np.abs(t["K"]).max()
+    dense = oracle.assemble_dense(p.mesh.num_nodes, p.conn_flat, ke)
+    assert np.array_equal(dense, K.toarray())  # CSR holds exactly the dense scatter's values
+    A, b = oracle.reduce_system(K, p.u_known, p.u_in, p.f_in)
+    assert np.abs(b - t["b"]).max() <= 1e-12 * np.abs(t["b"]).max()
+    Kff, b2 = oracle.partition_dense(dense, p.u_known, p.u_in, p.f_in)
+    assert np.array_equal(b, b2)
+    assert np.array_equal(oracle.sparsify_dense(Kff).toarray(), A.toarray())
+    assert np.array_equal(Kff, t["K"][np.ix_(t["free"], t["free"])] * 0 + Kff)  # shape check
+    # CG (to round-off: absolute 1e-4 on a 1e10-scale rhs) against the direct solve
+    r = run(p, "sparse")
+    assert rel(r["u"], t["u"]) <= 1e-9
+    fs = np.abs(t["K"]).max() * np.abs(t["u"]).max()
+    assert np.abs(r["f"] - t["f"]).max() <= 1e-9 * fs
+    stable = np.abs(t["stress"]) > 1e-6 * np.abs(t["stress"]).max()
+    assert np.allclose(r["stress"][stable], t["stress"][stable], rtol=1e-6)
+
+
+def test_patch_test_uniform_tension(built):
+    """CST reproduces a linear field exactly: left edge ux=0 (one node also uy=0), right edge ux=delta =>
+    ux = delta x / L, uy = -nu delta (y - y0) / L, sigma_x = E delta / L everywhere."""
+    L, H, delta = 2.0, 1.0, 1e-3
+    m = meshgen.shuffle(meshgen.perturb(meshgen.plate(8, 4, L, H), 0.2), 4)
+    eps = 1e-9
+    rules = [meshgen.BoundaryRule("left", x_max=eps, ux=0.0, fy=0.0),
+             meshgen.BoundaryRule("pin", x_max=eps, y_max=eps, ux=0.0, uy=0.0),
+             meshgen.BoundaryRule("right", x_min=L - eps, ux=delta, fy=0.0)]
+    p = meshgen.apply_boundary_rules(m, rules)
+    r = run(p, "dense")
+    ux = delta * m.xy[:, 0] / L
+    uy = -p.poisson_ratio * delta * m.xy[:, 1] / L
+    want = np.stack([ux, uy], axis=1).reshape(-1)
+    assert np.abs(r["u"] - want).max() <= 1e-9 * delta
+    assert np.allclose(r["stress"], p.youngs_modulus * delta / L, rtol=1e-8)
+    # total reaction on the right edge = sigma * H * t
+    right = np.where(m.xy[:, 0] > L - eps)[0]
+    assert r["f"][2 * right].sum() == pytest.approx(p.youngs_modulus * delta / L * H * p.part_thickness, rel=1e-8)
+
+
+def test_cg_restatement_semantics(built):
+    p = CASES["plate"]()
+    K = oracle.assemble_sparse(p.xy_flat, p.conn_flat, p.poisson_ratio, p.youngs_modulus, p.part_thickness)
+    A, b = oracle.reduce_system(K, p.u_known, p.u_in, p.f_in)
+    x, it, cost, hist = oracle.cg(A, b, hist_len=1000)
+    # stops after the FIRST iteration whose cost is <= target (solver.rs:154), absolute threshold
+    assert cost <= oracle.TARGET_CG_COST and np.all(hist[:it - 1] > oracle.TARGET_CG_COST) and hist[it - 1] == cost
+    # cost is the recurrence residual norm; the true residual agrees to round-off of the rhs scale
+    assert np.linalg.norm(A.spmv(x) - b) <= 1e-10 * np.linalg.norm(b)
+    # first iteration by hand: r0=-b, p0=b, alpha=b.b/(b.Ab), r1=r0+alpha A p0
+    Ab = A.spmv(b)
+    alpha = (b @ b) / (b @ Ab)
+    assert hist[0] == pytest.approx(np.linalg.norm(-b + alpha * Ab), rel=1e-12)
+    # r.r variant stops earlier; relative variant
+    _, it_sq, cost_sq, _ = oracle.cg(A, b, stop_mode=oracle.STOP_RNORM_SQ)
+    assert it_sq <= it and cost_sq <= 1e-4
+    _, it_rel, cost_rel, _ = oracle.cg(A, b, stop_mode=oracle.STOP_REL, tol=1e-6)
+    assert it_rel < it and cost_rel <= 1e-6 * np.linalg.norm(b)
+    # max_iters (solver.rs:153) returns the best iterate so far
+    xb, itb, costb, hb = oracle.cg(A, b, max_iter=5, hist_len=5)
+    assert itb == 5 and costb == hb.min()
+    # zero right-hand side: documented deviation, x = 0 in 0 iterations
+    x0, it0, c0, _ = oracle.cg(A, np.zeros_like(b))
+    assert it0 == 0 and c0 == 0.0 and not x0.any()
+
+
+def test_clockwise_mesh_same_displacements_for_displacement_loading(built):
+    """K -> -K and b -> -b when every element is reversed and all loads are prescribed displacements."""
+    a = run(meshgen.config_fixed_left_pull_right(meshgen.plate(8)), "dense")
+    b = run(CASES["clockwise"](), "dense")
+    assert rel(b["u"], a["u"]) <= 1e-10
+
+
+@pytest.mark.parametrize("name", ["tensile", "plate"])
+def test_oracle_reproduces_golden_fixture(built, name):
+    """tests/golden/*.npz were written by tests/golden/make_fixtures.py from this oracle: bit-for-bit or the
+    oracle has drifted."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    E, nu, t = g["material"]
+    r = oracle.run(g["xy"].reshape(-1), g["conn"].reshape(-1), g["u_known"], g["u_in"], g["f_in"], E, nu, t,
+                   path="sparse", hist_len=32)
+    for k in ("u", "f", "stress", "history"):
+        assert np.array_equal(r[k], g[k]), k
+    assert r["iterations"] == int(g["iterations"]) and r["nnz_ff"] == int(g["nnz_ff"])
+
+
+def test_tensile_example_physics(built):
+    """examples/tensile-example: right grip moves by exactly ux=3 (input.json:27-28), the specimen necks
+    symmetrically (media/tensilve-results.png), left grip stays put."""
+    g = np.load(os.path.join(GOLD, "tensile.npz"))
+    xy, u = g["xy"], g["u"].reshape(-1, 2)
+    assert np.all(u[xy[:, 0] > 10][:, 0] == 3.0)
+    assert np.all(u[xy[:, 0] < -10] == 0.0)
+    gauge = np.abs(xy[:, 0]) < 3
+    top, bot = gauge & (xy[:, 1] > 2.0), gauge & (xy[:, 1] < -2.0)
+    assert u[top][:, 1].mean() < 0 < u[bot][:, 1].mean()  # lateral contraction
+    assert abs(u[top][:, 1].mean() + u[bot][:, 1].mean()) < 0.05 * abs(u[top][:, 1].mean())
+    # every element was reversed by check_ccw (area < 1.0), so K is negative definite and CG still converged
+    a = xy[g["conn"]]
+    area = 0.5 * ((a[:, 1, 0] - a[:, 0, 0]) * (a[:, 2, 1] - a[:, 0, 1]) - (a[:, 2, 0] - a[:, 0, 0]) * (a[:, 1, 1] - a[:, 0, 1]))
+    assert np.all(area < 0) and float(g["final_cost"]) <= 1e-4
