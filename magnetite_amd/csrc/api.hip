@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -83,6 +84,10 @@ struct mag_ctx {
     int32_t cap = 0, max_halo = 0;
     int64_t halo_total = 0;
     DevBuf hcnt, hoffn, hk0, hk1, halo_g, tile_hcnt, tile_hoff;
+    // multi-GPU partition: this rank owns tiles [t0,t1) = nodes [own0,own1) of the Hilbert order
+    int32_t t0 = 0, t1 = 0, own0 = 0, own1 = 0, n_iface = 0;
+    bool dist = false; // CG runs the distributed protocol (nranks > 1, or forced for a 1-rank rehearsal)
+    DevBuf iface, comm_pq, comm_rr;
 
     // CSR of K (caller numbering)
     int64_t nb = 0;
@@ -286,6 +291,45 @@ int ensure_order(mag_ctx *ctx)
             ctx->halo_total += hc[t];
         }
     }
+    // ---- partition: contiguous tile ranges of the Hilbert order, identical arithmetic on every rank ----
+    {
+        const int R = ctx->comm.nranks, me = ctx->comm.rank;
+        auto tile_lo = [&](int s_) { return (int32_t)(((int64_t)T * s_) / R); };
+        ctx->t0 = tile_lo(me);
+        ctx->t1 = tile_lo(me + 1);
+        ctx->own0 = (int32_t)std::min<int64_t>((int64_t)ctx->t0 * B, N);
+        ctx->own1 = (int32_t)std::min<int64_t>((int64_t)ctx->t1 * B, N);
+        ctx->dist = R > 1 || getenv("MAG_TUNE_FORCE_DIST") != nullptr;
+        ctx->n_iface = 0;
+        if (R > 1 && ctx->t1 <= ctx->t0)
+            return fail(ctx, MAG_ERR_BAD_ARGS, "mesh has %d tiles, fewer than %d ranks", (int)T, R);
+        if (R > 1) {
+            // interface = every node some rank reads (tile halo) but does not own; every rank derives the same
+            // sorted list from the replicated symbolic data, so no communication is needed to agree on it
+            std::vector<int32_t> hoff((size_t)T + 1), hg((size_t)std::max<int64_t>(ctx->halo_total, 1));
+            HIPCHK(hipMemcpyAsync(hoff.data(), ctx->tile_hoff.p, 4 * ((size_t)T + 1), hipMemcpyDeviceToHost, s));
+            if (ctx->halo_total > 0)
+                HIPCHK(hipMemcpyAsync(hg.data(), ctx->halo_g.p, 4 * (size_t)ctx->halo_total, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            std::vector<int32_t> iface;
+            for (int r_ = 0; r_ < R; ++r_) {
+                const int64_t lo = std::min<int64_t>((int64_t)tile_lo(r_) * B, N);
+                const int64_t hi = std::min<int64_t>((int64_t)tile_lo(r_ + 1) * B, N);
+                for (int32_t t = tile_lo(r_); t < tile_lo(r_ + 1); ++t)
+                    for (int32_t k = hoff[t]; k < hoff[t + 1]; ++k)
+                        if (hg[k] < lo || hg[k] >= hi) iface.push_back(hg[k]);
+            }
+            std::sort(iface.begin(), iface.end());
+            iface.erase(std::unique(iface.begin(), iface.end()), iface.end());
+            ctx->n_iface = (int32_t)iface.size();
+            HIPCHK(ctx->iface.reserve(4 * (iface.size() + 1)));
+            if (!iface.empty())
+                HIPCHK(hipMemcpyAsync(ctx->iface.p, iface.data(), 4 * iface.size(), hipMemcpyHostToDevice, s));
+            HIPCHK(hipStreamSynchronize(s)); // iface (host vector) must outlive the copy
+        }
+        HIPCHK(ctx->comm_pq.reserve(64));
+        HIPCHK(ctx->comm_rr.reserve(8 * (1 + 2 * (size_t)ctx->n_iface) + 64));
+    }
     ctx->max_halo = max_halo;
     ctx->cap = ((B + max_halo + 31) / 32) * 32;
     ctx->use_lds = ctx->opt.op_variant != 1 && ctx->cap <= magk::kMaxLdsNodes;
@@ -375,6 +419,10 @@ magk::OpParams op_params(mag_ctx *ctx)
     magk::OpParams P = {};
     P.N = ctx->N;
     P.T = ctx->T;
+    P.t0 = 0; // plain applications (RHS, reactions, tests) always cover the whole mesh
+    P.t1 = ctx->T;
+    P.own0 = 0;
+    P.own1 = (int32_t)ctx->N;
     P.nPart = magk::cg_grid(ctx->T);
     P.xyP = ctx->xyP.as<double2>();
     P.maskP = ctx->maskP.as<uint8_t>();
@@ -427,11 +475,19 @@ int reserve_cg(mag_ctx *ctx)
 void iteration_params(mag_ctx *ctx, int parity, magk::OpParams &P, magk::UpdParams &U)
 {
     P = op_params(ctx);
+    P.t0 = ctx->t0;
+    P.t1 = ctx->t1;
+    P.own0 = ctx->own0;
+    P.own1 = ctx->own1;
+    P.iface = ctx->iface.as<int32_t>();
+    P.n_iface = ctx->n_iface;
+    P.nPart = ctx->dist ? 1 : magk::cg_grid(ctx->t1 - ctx->t0);
     P.r = ctx->r.as<double2>();
     P.pprev = parity ? ctx->p0.as<double2>() : ctx->p1.as<double2>();
     P.pnew = parity ? ctx->p1.as<double2>() : ctx->p0.as<double2>();
     P.q = ctx->q.as<double2>();
-    P.partRR = ctx->partRR.as<double>();
+    // distributed: the dots arrive all-reduced in comm_rr[0] / comm_pq[0]; kernels still write local partials
+    P.partRR = ctx->dist ? ctx->comm_rr.as<double>() : ctx->partRR.as<double>();
     P.partPQ = ctx->partPQ.as<double>();
     P.st = ctx->state.as<CgState>();
     P.hist = ctx->hist.as<double>();
@@ -440,11 +496,13 @@ void iteration_params(mag_ctx *ctx, int parity, magk::OpParams &P, magk::UpdPara
     U.N = ctx->N;
     U.T = ctx->T;
     U.nPart = P.nPart;
+    U.t0 = ctx->t0;
+    U.t1 = ctx->t1;
     U.x = ctx->x.as<double2>();
     U.r = ctx->r.as<double2>();
     U.p = P.pnew;
     U.q = ctx->q.as<double2>();
-    U.partPQ = ctx->partPQ.as<double>();
+    U.partPQ = ctx->dist ? ctx->comm_pq.as<double>() : ctx->partPQ.as<double>();
     U.partRR = ctx->partRR.as<double>();
     U.st = ctx->state.as<CgState>();
     U.wt = ctx->tune_wt;
@@ -453,12 +511,32 @@ void iteration_params(mag_ctx *ctx, int parity, magk::OpParams &P, magk::UpdPara
 // one block of G CG iterations on the stream (parity 0 first: p_prev = p1, p_new = p0)
 int launch_block(mag_ctx *ctx, int G)
 {
+    const int nloc = magk::cg_grid(ctx->t1 - ctx->t0);
     for (int i = 0; i < G; ++i) {
         magk::OpParams P;
         magk::UpdParams U;
         iteration_params(ctx, i & 1, P, U);
         magk::op_launch(P, ctx->B, true, ctx->stream);
+        if (ctx->dist) {
+            // p.q: sum of this rank's partials -> comm_pq[0] -> sum over ranks
+            magk::iface_pack(ctx->partPQ.as<double>(), nloc, nullptr, nullptr, 0, 0, 0, ctx->comm_pq.as<double>(),
+                             ctx->stream);
+            std::string msg;
+            if (int rc = ctx->comm.allreduce_sum(ctx->comm_pq.as<double>(), 1, ctx->stream, msg))
+                return fail(ctx, rc, "%s", msg.c_str());
+        }
         magk::upd_launch(U, ctx->B, ctx->stream);
+        if (ctx->dist) {
+            // one buffer: [r.r partial sum | r on the interface nodes this rank owns], summed over ranks,
+            // then the other ranks' interface residuals are written into this rank's copy of r
+            magk::iface_pack(ctx->partRR.as<double>(), nloc, ctx->r.as<double2>(), ctx->iface.as<int32_t>(),
+                             ctx->n_iface, ctx->own0, ctx->own1, ctx->comm_rr.as<double>(), ctx->stream);
+            std::string msg;
+            if (int rc = ctx->comm.allreduce_sum(ctx->comm_rr.as<double>(), 1 + 2 * (int64_t)ctx->n_iface, ctx->stream, msg))
+                return fail(ctx, rc, "%s", msg.c_str());
+            magk::iface_unpack(ctx->comm_rr.as<double>(), ctx->iface.as<int32_t>(), ctx->n_iface, ctx->own0,
+                               ctx->own1, ctx->r.as<double2>(), ctx->stream);
+        }
     }
     HIPCHK(hipGetLastError());
     return MAG_OK;
@@ -511,13 +589,24 @@ int cg_phase(mag_ctx *ctx)
     HIPCHK(hipMemsetAsync(ctx->x.p, 0, vb, s));
     HIPCHK(hipMemsetAsync(ctx->p0.p, 0, vb, s));
     HIPCHK(hipMemsetAsync(ctx->p1.p, 0, vb, s));
-    magk::cg_init(ctx->bP.as<double2>(), ctx->r.as<double2>(), ctx->N, ctx->B, ctx->T, ctx->partRR.as<double>(), s);
-    magk::cg_setup(ctx->partRR.as<double>(), magk::cg_grid(ctx->T), ctx->opt.stop_mode, ctx->opt.tol,
-                   (long long)ctx->opt.max_iter, ctx->state.as<CgState>(), s);
+    magk::cg_init(ctx->bP.as<double2>(), ctx->r.as<double2>(), ctx->N, ctx->B, ctx->T, ctx->t0, ctx->t1,
+                  ctx->partRR.as<double>(), s);
+    if (ctx->dist) {
+        magk::iface_pack(ctx->partRR.as<double>(), magk::cg_grid(ctx->T), nullptr, nullptr, 0, 0, 0,
+                         ctx->comm_rr.as<double>(), s);
+        std::string msg;
+        if (int rc = ctx->comm.allreduce_sum(ctx->comm_rr.as<double>(), 1, s, msg)) return fail(ctx, rc, "%s", msg.c_str());
+        magk::cg_setup(ctx->comm_rr.as<double>(), 1, ctx->opt.stop_mode, ctx->opt.tol, (long long)ctx->opt.max_iter,
+                       ctx->state.as<CgState>(), s);
+    } else {
+        magk::cg_setup(ctx->partRR.as<double>(), magk::cg_grid(ctx->T), ctx->opt.stop_mode, ctx->opt.tol,
+                       (long long)ctx->opt.max_iter, ctx->state.as<CgState>(), s);
+    }
     HIPCHK(hipGetLastError());
 
     const int G = ctx->opt.check_every;
-    const bool graph = ctx->opt.use_graph != 0;
+    // the distributed block carries collectives (and, with the test transport, host round trips): launched eagerly
+    const bool graph = ctx->opt.use_graph != 0 && !ctx->dist;
     if (graph)
         if (int rc = ensure_graph(ctx, G)) return rc;
     const long long max_blocks = (long long)(ctx->opt.max_iter / G) + 3;
@@ -536,6 +625,12 @@ int cg_phase(mag_ctx *ctx)
             done = ctx->h_state[slot ^ 1].done != 0;
         }
         slot ^= 1;
+    }
+    if (ctx->dist) {
+        // assemble the full solution on every rank: each contributes its own nodes, zeros elsewhere
+        magk::zero_unowned(ctx->x.as<double2>(), ctx->N, ctx->own0, ctx->own1, s);
+        std::string msg;
+        if (int rc = ctx->comm.allreduce_sum(ctx->x.as<double>(), 2 * ctx->N, s, msg)) return fail(ctx, rc, "%s", msg.c_str());
     }
     HIPCHK(hipMemcpyAsync(&ctx->h_state[2], ctx->state.p, sizeof(CgState), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -627,7 +722,7 @@ void mag_destroy(mag_ctx *ctx)
                           &ctx->sK0, &ctx->sK1, &ctx->sV0, &ctx->sV1, &ctx->perm, &ctx->iperm, &ctx->xyP,
                           &ctx->maskP, &ctx->deg, &ctx->inc_off, &ctx->inc, &ctx->tile_deg, &ctx->tile_cnt,
                           &ctx->tile_off, &ctx->ell, &ctx->hcnt, &ctx->hoffn, &ctx->hk0, &ctx->hk1, &ctx->halo_g,
-                          &ctx->tile_hcnt, &ctx->tile_hoff, &ctx->pk0, &ctx->pk1, &ctx->pv0, &ctx->pv1, &ctx->head,
+                          &ctx->tile_hcnt, &ctx->tile_hoff, &ctx->iface, &ctx->comm_pq, &ctx->comm_rr, &ctx->pk0, &ctx->pk1, &ctx->pv0, &ctx->pv1, &ctx->head,
                           &ctx->blk, &ctx->rowcnt, &ctx->seg_start, &ctx->bptr, &ctx->bcol, &ctx->kval, &ctx->ke,
                           &ctx->isfree, &ctx->fidx, &ctx->rcnt, &ctx->rowoff, &ctx->rp_ff, &ctx->col_ff,
                           &ctx->val_ff, &ctx->b_ff, &ctx->rp_full, &ctx->col_full, &ctx->x, &ctx->r, &ctx->p0,

@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(B) k_operator(const OpParams P)
 
     const double c0 = P.c0, nu = P.nu, h = P.h;
     double acc = 0.0;
-    for (int32_t t = blockIdx.x; t < P.T; t += gridDim.x) {
+    for (int32_t t = P.t0 + blockIdx.x; t < P.t1; t += gridDim.x) {
         const int64_t base = (int64_t)t * B;
         const int64_t node = base + threadIdx.x;
         const bool valid = node < P.N;
@@ -231,6 +231,13 @@ __global__ void __launch_bounds__(B) k_operator(const OpParams P)
         }
     }
     if (CG) {
+        for (int32_t k = blockIdx.x * B + threadIdx.x; k < P.n_iface; k += gridDim.x * B) {
+            const int32_t g = P.iface[k];
+            if (g < P.own0 || g >= P.own1) {
+                const double2 r2 = P.r[g], pp = P.pprev[g];
+                P.pnew[g] = make_double2(-r2.x + beta * pp.x, -r2.y + beta * pp.y);
+            }
+        }
         const double tot = block_sum<B>(acc, s_red);
         if (threadIdx.x == 0) P.partPQ[blockIdx.x] = tot;
     }
@@ -297,7 +304,7 @@ __global__ void __launch_bounds__(B) k_operator_lds(const OpParams P)
         }
     };
 
-    load_tile(blockIdx.x);
+    load_tile(P.t0 + blockIdx.x);
 
     double beta = 0.0;
     if (CG) {
@@ -330,7 +337,7 @@ __global__ void __launch_bounds__(B) k_operator_lds(const OpParams P)
 
     const double c0 = P.c0, nu = P.nu, h = P.h;
     double acc = 0.0;
-    int32_t t = blockIdx.x;
+    int32_t t = P.t0 + blockIdx.x;
     for (;;) {
         double2 pa;
         if (CG) {
@@ -417,10 +424,18 @@ __global__ void __launch_bounds__(B) k_operator_lds(const OpParams P)
             }
         }
         t += gridDim.x;
-        if (t >= P.T) break;
+        if (t >= P.t1) break;
         load_tile(t);
     }
     if (CG) {
+        // multi-GPU: p of the interface nodes other ranks own is advanced locally from their (exchanged) r
+        for (int32_t k = blockIdx.x * B + tid; k < P.n_iface; k += gridDim.x * B) {
+            const int32_t g = P.iface[k];
+            if (g < P.own0 || g >= P.own1) {
+                const double2 r2 = P.r[g], pp = P.pprev[g];
+                P.pnew[g] = make_double2(-r2.x + beta * pp.x, -r2.y + beta * pp.y);
+            }
+        }
         const double tot = block_sum<B>(acc, s_red);
         if (tid == 0) P.partPQ[blockIdx.x] = tot;
     }
@@ -430,7 +445,7 @@ size_t op_lds_bytes(int32_t cap, int32_t B) { return (size_t)cap * 32 + (size_t)
 
 void op_launch(const OpParams &P, int32_t B, bool cg_mode, hipStream_t s)
 {
-    const int grid = cg_grid(P.T);
+    const int grid = cg_grid(P.t1 - P.t0);
     if (P.ell16) {
         const size_t lds = op_lds_bytes(P.cap, B);
 #define MAG_OPL(BB)                                                       \
@@ -475,7 +490,7 @@ __global__ void __launch_bounds__(B) k_update(const UpdParams P)
     const int done = st->done;
     const long long k = st->iterB;
     // first tile's operands are in flight while the p.q partials are reduced
-    int32_t t = blockIdx.x;
+    int32_t t = P.t0 + blockIdx.x;
     int64_t node = (int64_t)t * B + threadIdx.x;
     double2 p = make_double2(0.0, 0.0), q = p, x = p, r = p;
     if (node < P.N) {
@@ -499,7 +514,7 @@ __global__ void __launch_bounds__(B) k_update(const UpdParams P)
             acc += r.x * r.x + r.y * r.y;
         }
         t += gridDim.x;
-        if (t >= P.T) break;
+        if (t >= P.t1) break;
         node = (int64_t)t * B + threadIdx.x;
         if (node < P.N) {
             p = P.p[node];
@@ -520,7 +535,7 @@ __global__ void __launch_bounds__(B) k_update(const UpdParams P)
 
 void upd_launch(const UpdParams &P, int32_t B, hipStream_t s)
 {
-    const int grid = cg_grid(P.T);
+    const int grid = cg_grid(P.t1 - P.t0);
 #define MAG_UPD(BB)                                  \
     if (P.wt)                                        \
         k_update<BB, true><<<grid, BB, 0, s>>>(P);   \
@@ -540,32 +555,94 @@ void upd_launch(const UpdParams &P, int32_t B, hipStream_t s)
 // argmin init: r0 = -(b - A x0) with x0 = 0 (solver.rs:143) => r0 = -b; p0 = -r0 comes out of the
 // first operator launch (beta = 1, p_prev = 0).
 template <int B>
-__global__ void __launch_bounds__(B) k_cg_init(const double2 *bP, double2 *r, int64_t N, int32_t T, double *partRR)
+__global__ void __launch_bounds__(B) k_cg_init(const double2 *bP, double2 *r, int64_t N, int32_t T, int32_t t0,
+                                               int32_t t1, double *partRR)
 {
     __shared__ double s_red[B / 64];
     double acc = 0.0;
+    // every rank holds the full right-hand side, so ghost residuals start correct without an exchange
     for (int32_t t = blockIdx.x; t < T; t += gridDim.x) {
         const int64_t node = (int64_t)t * B + threadIdx.x;
         if (node < N) {
             const double2 b = bP[node];
             const double2 v = make_double2(-b.x, -b.y);
             r[node] = v;
-            acc += v.x * v.x + v.y * v.y;
+            if (t >= t0 && t < t1) acc += v.x * v.x + v.y * v.y;
         }
     }
     const double tot = block_sum<B>(acc, s_red);
     if (threadIdx.x == 0) partRR[blockIdx.x] = tot;
 }
 
-void cg_init(const double2 *bP, double2 *r, int64_t N, int32_t B, int32_t T, double *partRR, hipStream_t s)
+void cg_init(const double2 *bP, double2 *r, int64_t N, int32_t B, int32_t T, int32_t t0, int32_t t1, double *partRR,
+             hipStream_t s)
 {
     const int grid = cg_grid(T);
     if (B == 256)
-        k_cg_init<256><<<grid, 256, 0, s>>>(bP, r, N, T, partRR);
+        k_cg_init<256><<<grid, 256, 0, s>>>(bP, r, N, T, t0, t1, partRR);
     else if (B == 1024)
-        k_cg_init<1024><<<grid, 1024, 0, s>>>(bP, r, N, T, partRR);
+        k_cg_init<1024><<<grid, 1024, 0, s>>>(bP, r, N, T, t0, t1, partRR);
     else
-        k_cg_init<512><<<grid, 512, 0, s>>>(bP, r, N, T, partRR);
+        k_cg_init<512><<<grid, 512, 0, s>>>(bP, r, N, T, t0, t1, partRR);
+}
+
+// ---------------------------------------------- multi-GPU pack / unpack ---
+// buf[0] = sum of this rank's dot partials; buf[1 + 2k ..] = value at interface node k if this rank owns it, else 0.
+// Summed over ranks (one all-reduce) it carries the global dot product and every interface value.
+__global__ void __launch_bounds__(256) k_iface_pack(const double *part, int nPart, const double2 *v,
+                                                    const int32_t *iface, int32_t n_iface, int32_t own0,
+                                                    int32_t own1, double *buf)
+{
+    __shared__ double s_red[4];
+    if (blockIdx.x == 0) {
+        const double tot = sum_partials<256>(part, nPart, s_red);
+        if (threadIdx.x == 0) buf[0] = tot;
+    }
+    for (int32_t k = blockIdx.x * 256 + threadIdx.x; k < n_iface; k += gridDim.x * 256) {
+        const int32_t g = iface[k];
+        const bool mine = g >= own0 && g < own1;
+        const double2 val = mine ? v[g] : make_double2(0.0, 0.0);
+        buf[1 + 2 * k] = val.x;
+        buf[2 + 2 * k] = val.y;
+    }
+}
+
+void iface_pack(const double *part, int nPart, const double2 *v, const int32_t *iface, int32_t n_iface, int32_t own0,
+                int32_t own1, double *buf, hipStream_t s)
+{
+    int grid = (n_iface + 255) / 256;
+    grid = grid < 1 ? 1 : (grid > 256 ? 256 : grid);
+    k_iface_pack<<<grid, 256, 0, s>>>(part, nPart, v, iface, n_iface, own0, own1, buf);
+}
+
+__global__ void __launch_bounds__(256) k_iface_unpack(const double *buf, const int32_t *iface, int32_t n_iface,
+                                                      int32_t own0, int32_t own1, double2 *v)
+{
+    for (int32_t k = blockIdx.x * 256 + threadIdx.x; k < n_iface; k += gridDim.x * 256) {
+        const int32_t g = iface[k];
+        if (g < own0 || g >= own1) v[g] = make_double2(buf[1 + 2 * k], buf[2 + 2 * k]);
+    }
+}
+
+void iface_unpack(const double *buf, const int32_t *iface, int32_t n_iface, int32_t own0, int32_t own1, double2 *v,
+                  hipStream_t s)
+{
+    if (n_iface <= 0) return;
+    int grid = (n_iface + 255) / 256;
+    grid = grid > 256 ? 256 : grid;
+    k_iface_unpack<<<grid, 256, 0, s>>>(buf, iface, n_iface, own0, own1, v);
+}
+
+// x of the other ranks' nodes is zeroed so that a sum all-reduce assembles the full solution
+__global__ void __launch_bounds__(256) k_zero_unowned(double2 *x, int64_t N, int64_t own0, int64_t own1)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < N && (i < own0 || i >= own1)) x[i] = make_double2(0.0, 0.0);
+}
+
+void zero_unowned(double2 *x, int64_t N, int64_t own0, int64_t own1, hipStream_t s)
+{
+    k_zero_unowned<<<(int)((N + 255) / 256), 256, 0, s>>>(x, N, own0, own1);
 }
 
 __global__ void __launch_bounds__(256) k_cg_setup(const double *partRR, int nPart, int stop_mode, double tol,

@@ -114,8 +114,13 @@ struct CgState {
 
 struct OpParams {
     int64_t N;
-    int32_t T; // tiles
+    int32_t T; // tiles of the whole mesh
     int32_t nPart;
+    int32_t t0, t1;   // tile range this rank owns (0, T on one GPU)
+    int32_t own0, own1; // node range of those tiles
+    const int32_t *iface; // multi-GPU: sorted Hilbert ids of every node some rank reads but does not own
+    int32_t n_iface;
+    int32_t pad1;
     const double2 *xyP;
     const uint8_t *maskP;
     const int32_t *tile_deg;
@@ -148,6 +153,7 @@ struct UpdParams {
     int64_t N;
     int32_t T;
     int32_t nPart;
+    int32_t t0, t1;
     double2 *x;
     double2 *r;
     const double2 *p;
@@ -163,7 +169,14 @@ int cg_grid(int32_t T);
 void op_launch(const OpParams &P, int32_t B, bool cg_mode, hipStream_t s);
 void upd_launch(const UpdParams &P, int32_t B, hipStream_t s);
 // r = -bP, x = 0 handled by caller memset; writes partRR
-void cg_init(const double2 *bP, double2 *r, int64_t N, int32_t B, int32_t T, double *partRR, hipStream_t s);
+void cg_init(const double2 *bP, double2 *r, int64_t N, int32_t B, int32_t T, int32_t t0, int32_t t1, double *partRR,
+             hipStream_t s);
+// multi-GPU: one buffer per all-reduce, [dot partial sum | interface values]
+void iface_pack(const double *part, int nPart, const double2 *v, const int32_t *iface, int32_t n_iface, int32_t own0,
+                int32_t own1, double *buf, hipStream_t s);
+void iface_unpack(const double *buf, const int32_t *iface, int32_t n_iface, int32_t own0, int32_t own1, double2 *v,
+                  hipStream_t s);
+void zero_unowned(double2 *x, int64_t N, int64_t own0, int64_t own1, hipStream_t s);
 // one block: bb = sum(partRR), thresholds, counters
 void cg_setup(const double *partRR, int32_t nPart, int stop_mode, double tol, long long max_iter, CgState *st,
               hipStream_t s);

@@ -114,6 +114,36 @@ class Context:
             raise MagnetiteError("Solver", self._L.mag_last_error(self._h).decode(), rc)
         return rc
 
+    # -- multi-GPU: one process per GPU ------------------------------------------
+    def init_rccl_from_torch(self, dist, rank, world):
+        """RCCL communicator for the library's own stream; torch.distributed only carries the 128-byte id."""
+        import torch
+        ident = (C.c_uint8 * _lib.MAG_UNIQUE_ID_BYTES)()
+        if rank == 0:
+            rc = self._L.mag_comm_get_unique_id(C.cast(ident, C.c_void_p))
+            if rc != MAG_OK:
+                raise MagnetiteError("Solver", "mag_comm_get_unique_id failed (librccl not loadable?)", rc)
+        t = torch.tensor(list(bytes(ident)), dtype=torch.uint8, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.broadcast(t, src=0)
+        raw = bytes(t.cpu().tolist())
+        buf = (C.c_uint8 * _lib.MAG_UNIQUE_ID_BYTES).from_buffer_copy(raw)
+        self._check(self._L.mag_comm_init_rccl(self._h, C.cast(buf, C.c_void_p), world, rank))
+
+    def init_callback(self, fn, rank, world):
+        """Test transport: fn(numpy_view) must sum the array over ranks in place (e.g. gloo all_reduce)."""
+        import numpy as _np
+
+        def _cb(user, ptr, count):
+            try:
+                fn(_np.ctypeslib.as_array(ptr, shape=(count,)))
+                return 0
+            except Exception as exc:  # pragma: no cover - surfaced as MAG_ERR_RCCL
+                print("allreduce callback failed:", exc, flush=True)
+                return 1
+
+        self._cb = _lib.ALLREDUCE_FN(_cb)  # keep alive
+        self._check(self._L.mag_comm_init_callback(self._h, world, rank, self._cb, None))
+
     # -- problem ---------------------------------------------------------------
     def upload(self, xy, conn, u_known, u_in, f_in, youngs_modulus, poisson_ratio, part_thickness):
         xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1)

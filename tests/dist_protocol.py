@@ -1,0 +1,102 @@
+"""CPU restatement of the multi-GPU CG protocol of magnetite_amd/csrc/api.hip (launch_block, cg_phase), run with
+world_size ranks over gloo.  Each rank owns a contiguous range of nodes of a spatial ordering and applies only ITS
+rows of K_ff (oracle CSR); per iteration exactly the library's two collectives are issued:
+    all_reduce([p.q partial])                       after the operator
+    all_reduce([r.r partial | r on interface nodes]) after the update
+ghost p is advanced locally from the exchanged r (p = -r + beta p), and the solution is assembled by a final
+all-reduce.  Checks the result against the single-process oracle CG."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import scipy.sparse as sp
+    import torch
+    import torch.distributed as dist
+
+    import oracle
+    from magnetite_amd import meshgen
+
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    p = meshgen.config_fixed_left_pull_right(meshgen.shuffle(meshgen.plate_with_holes(20, 30, 1.0, 1.5), 5))
+    N = p.mesh.num_nodes
+    K = oracle.assemble_sparse(p.xy_flat, p.conn_flat, p.poisson_ratio, p.youngs_modulus, p.part_thickness)
+    Kf = sp.csr_matrix((K.val, K.col, K.rowptr), shape=(K.n, K.n))
+    free = (p.u_known == 0)
+    M = sp.diags(free.astype(np.float64))
+    A = (M @ Kf @ M).tocsr()                      # K_ff embedded in full length, as the GPU operator applies it
+    b = np.where(free, p.f_in - Kf @ np.where(free, 0.0, p.u_in), 0.0)
+
+    # ordering + contiguous ranges (the library uses Hilbert order and tile granularity; any spatial order works here)
+    B = 16
+    order = np.lexsort((p.mesh.xy[:, 0], np.floor(p.mesh.xy[:, 1] * 6)))
+    T = (N + B - 1) // B
+    lo = [min((T * s // world) * B, N) for s in range(world + 1)]
+    owner_of_pos = np.searchsorted(lo, np.arange(N), side="right") - 1
+    owner = np.empty(N, dtype=np.int64)
+    owner[order] = owner_of_pos
+    dof_owner = np.repeat(owner, 2)
+    mine = dof_owner == rank
+    # interface: nodes read by a rank (columns of its rows) that it does not own -- union over ranks, sorted
+    node_adj = sp.csr_matrix((np.ones(K.nnz), K.col // 2, K.rowptr), shape=(K.n, N))
+    iface = set()
+    for s in range(world):
+        rows = np.where(dof_owner == s)[0]
+        cols = np.unique(node_adj[rows].indices)
+        iface.update(int(c) for c in cols if owner[c] != s)
+    iface = np.array(sorted(iface), dtype=np.int64)
+    iface_dofs = np.stack([2 * iface, 2 * iface + 1], axis=1).reshape(-1)
+    iface_mine = dof_owner[iface_dofs] == rank
+    Arows = A[np.where(mine)[0]]
+
+    def allreduce(v):
+        t = torch.from_numpy(v)
+        dist.all_reduce(t)
+        return v
+
+    x = np.zeros(K.n)
+    r = -b.copy()                                  # every rank starts from the full right-hand side
+    pp = np.zeros(K.n)
+    rr = allreduce(np.array([np.dot(r[mine], r[mine])]))[0]
+    rr_prev, it, target = rr, 0, 1e-4
+    while it < 100000:
+        if it >= 1 and np.sqrt(rr) <= target:
+            break
+        beta = rr / rr_prev if it > 0 else 1.0
+        pn = np.zeros(K.n)
+        pn[mine] = -r[mine] + beta * pp[mine]
+        notmine_if = iface_dofs[~iface_mine]
+        pn[notmine_if] = -r[notmine_if] + beta * pp[notmine_if]   # ghost p from exchanged r
+        q = Arows @ pn
+        pq = allreduce(np.array([np.dot(pn[mine], q)]))[0]
+        alpha = rr / pq
+        x[mine] += alpha * pn[mine]
+        r[mine] += alpha * q
+        buf = np.zeros(1 + iface_dofs.size)
+        buf[0] = np.dot(r[mine], r[mine])
+        buf[1:][iface_mine] = r[iface_dofs[iface_mine]]
+        allreduce(buf)
+        r[notmine_if] = buf[1:][~iface_mine]
+        rr_prev, rr, pp = rr, buf[0], pn
+        it += 1
+    x[~mine] = 0.0
+    allreduce(x)
+    u = np.where(free, x, p.u_in)
+    ref = oracle.run(p.xy_flat, p.conn_flat, p.u_known, p.u_in, p.f_in, p.youngs_modulus, p.poisson_ratio,
+                     p.part_thickness, path="sparse")
+    err = np.linalg.norm(u - ref["u"]) / np.linalg.norm(ref["u"])
+    print(f"rank {rank}/{world}: iface nodes {iface.size}, iterations {it} (oracle {ref['iterations']}), rel-L2 {err:.2e}",
+          flush=True)
+    ok = err <= 1e-8 and abs(it - ref["iterations"]) <= max(3, ref["iterations"] // 50) and iface.size > 0
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

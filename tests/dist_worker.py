@@ -1,0 +1,69 @@
+"""Multi-rank worker for tests/test_distributed_gpu.py (launched with torch.distributed.run, gloo rendezvous).
+
+mode callback : every rank drives the SAME GPU 0 through its own mag_ctx; the per-iteration all-reduces go through
+                the library's host-callback transport -> gloo.  Exercises the whole distributed CG path (tile-range
+                partition, interface list, pack / all-reduce / unpack, ghost-p recurrence, solution assembly) except
+                the RCCL call itself, which needs one GPU per rank.
+mode rccl1    : single rank, RCCL communicator of size 1, distributed protocol forced (MAG_TUNE_FORCE_DIST=1):
+                exercises dlopen(librccl), ncclCommInitRank, ncclAllReduce on the library's stream.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="callback")
+    ap.add_argument("--mesh", type=int, default=96)
+    a = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+
+    import oracle
+    from magnetite_amd import Context, meshgen
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    prob = meshgen.config_fixed_left_pull_right(meshgen.shuffle(meshgen.plate_with_holes(a.mesh, 2 * a.mesh, 1.0, 2.0), 3))
+    if a.mode == "rccl1":
+        os.environ["MAG_TUNE_FORCE_DIST"] = "1"
+        dist.init_process_group("gloo", rank=0, world_size=1, init_method="tcp://127.0.0.1:29533")
+        with Context(device=0, tile_nodes=256) as c:
+            c.init_rccl_from_torch(dist, 0, 1)
+            out = c.solve(prob)
+    else:
+        dist.init_process_group("gloo")
+
+        def allreduce(arr):
+            t = torch.from_numpy(arr)
+            dist.all_reduce(t)
+
+        with Context(device=0, tile_nodes=256) as c:
+            c.init_callback(allreduce, rank, world)
+            out = c.solve(prob)
+    ref = oracle.run(prob.xy_flat, prob.conn_flat, prob.u_known, prob.u_in, prob.f_in, prob.youngs_modulus,
+                     prob.poisson_ratio, prob.part_thickness, path="sparse")
+    err = np.linalg.norm(out["u"] - ref["u"]) / np.linalg.norm(ref["u"])
+    os.environ.pop("MAG_TUNE_FORCE_DIST", None)
+    with Context(device=0, tile_nodes=256) as c1:
+        single = c1.solve(prob)
+    err1 = np.linalg.norm(out["u"] - single["u"]) / np.linalg.norm(single["u"])
+    print(f"rank {rank}/{world} mode={a.mode} iters={out['iterations']} (single {single['iterations']}, oracle "
+          f"{ref['iterations']}) rel-L2 vs oracle {err:.2e} vs single-rank {err1:.2e}", flush=True)
+    ok = out["converged"] == 1 and err <= 1e-8 and err1 <= 1e-9 and abs(out["iterations"] - single["iterations"]) <= 5
+    # every rank holds the full, identical solution
+    if world > 1:
+        t = torch.from_numpy(out["u"].copy())
+        dist.broadcast(t, src=0)
+        ok = ok and np.array_equal(t.numpy(), out["u"])
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,28 @@
+"""-m gpu: the multi-rank CG path, rehearsed on ONE GPU (see tests/dist_worker.py for what each mode covers)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
+
+
+def launch(nproc, mode, port):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER, "--mode", mode]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+
+
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_ranks_sharing_one_gpu_through_gloo(built, nproc):
+    r = launch(nproc, "callback", 29540 + nproc)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_rccl_single_rank_communicator(built):
+    r = subprocess.run([sys.executable, WORKER, "--mode", "rccl1"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
