@@ -83,7 +83,7 @@ struct mag_ctx {
     int tune_wt = 1; // write-through stores in the CG kernels (MAG_TUNE_WT=0 to compare)
     int32_t cap = 0, max_halo = 0;
     int64_t halo_total = 0;
-    DevBuf hcnt, hoffn, hk0, hk1, halo_g, tile_hcnt, tile_hoff;
+    DevBuf hcnt, hoffn, hk0, hk1, halo_g, halo_xy, tile_hcnt, tile_hoff;
     // multi-GPU partition: this rank owns tiles [t0,t1) = nodes [own0,own1) of the Hilbert order
     int32_t t0 = 0, t1 = 0, own0 = 0, own1 = 0, n_iface = 0;
     bool dist = false; // CG runs the distributed protocol (nranks > 1, or forced for a 1-rank rehearsal)
@@ -334,6 +334,8 @@ int ensure_order(mag_ctx *ctx)
     ctx->cap = ((B + max_halo + 31) / 32) * 32;
     ctx->use_lds = ctx->opt.op_variant != 1 && ctx->cap <= magk::kMaxLdsNodes;
     if (ctx->use_lds) {
+        HIPCHK(ctx->halo_xy.reserve(16 * (size_t)std::max<int64_t>(ctx->halo_total, 1)));
+        magk::halo_coords(ctx->halo_g.as<int32_t>(), ctx->xyP.as<double>(), ctx->halo_total, ctx->halo_xy.as<double>(), s);
         HIPCHK(ctx->ell.reserve(4 * (size_t)(h_total > 0 ? h_total : 1)));
         magk::fill_ell16(ctx->inc_off.as<int32_t>(), ctx->inc.as<uint32_t>(), ctx->conn.as<int32_t>(),
                          ctx->iperm.as<int32_t>(), ctx->tile_deg.as<int32_t>(), ctx->tile_off.as<int64_t>(),
@@ -432,12 +434,12 @@ magk::OpParams op_params(mag_ctx *ctx)
         P.ell16 = ctx->ell.as<uint32_t>();
         P.tile_hoff = ctx->tile_hoff.as<int32_t>();
         P.halo_g = ctx->halo_g.as<int32_t>();
+        P.halo_xy = ctx->halo_xy.as<double2>();
         P.cap = ctx->cap;
     } else {
         P.ell = ctx->ell.as<int2>();
     }
     P.wt = ctx->tune_wt;
-    if (const char *e = getenv("MAG_TUNE_ABLATE")) P.ablate = atoi(e);
     P.c0 = ctx->youngs * ctx->thick / (2.0 * (1.0 - ctx->nu * ctx->nu));
     P.nu = ctx->nu;
     P.h = (1.0 - ctx->nu) / 2.0;
@@ -486,6 +488,7 @@ void iteration_params(mag_ctx *ctx, int parity, magk::OpParams &P, magk::UpdPara
     P.pprev = parity ? ctx->p0.as<double2>() : ctx->p1.as<double2>();
     P.pnew = parity ? ctx->p1.as<double2>() : ctx->p0.as<double2>();
     P.q = ctx->q.as<double2>();
+    P.x = ctx->x.as<double2>();
     // distributed: the dots arrive all-reduced in comm_rr[0] / comm_pq[0]; kernels still write local partials
     P.partRR = ctx->dist ? ctx->comm_rr.as<double>() : ctx->partRR.as<double>();
     P.partPQ = ctx->partPQ.as<double>();
@@ -498,9 +501,7 @@ void iteration_params(mag_ctx *ctx, int parity, magk::OpParams &P, magk::UpdPara
     U.nPart = P.nPart;
     U.t0 = ctx->t0;
     U.t1 = ctx->t1;
-    U.x = ctx->x.as<double2>();
     U.r = ctx->r.as<double2>();
-    U.p = P.pnew;
     U.q = ctx->q.as<double2>();
     U.partPQ = ctx->dist ? ctx->comm_pq.as<double>() : ctx->partPQ.as<double>();
     U.partRR = ctx->partRR.as<double>();
@@ -548,7 +549,7 @@ int ensure_graph(mag_ctx *ctx, int G)
     void *ptrs[] = {ctx->x.p,  ctx->r.p,      ctx->p0.p,     ctx->p1.p,    ctx->q.p,        ctx->partRR.p,
                     ctx->partPQ.p, ctx->state.p, ctx->hist.p,   ctx->xyP.p,   ctx->maskP.p,    ctx->tile_deg.p,
                     ctx->tile_off.p, ctx->ell.p, ctx->tile_hoff.p, ctx->halo_g.p,
-                    (void *)(intptr_t)(ctx->use_lds ? ctx->cap : -1)};
+                    (void *)(intptr_t)(ctx->use_lds ? ctx->cap : -1), ctx->halo_xy.p};
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) k.ptrs[i] = ptrs[i];
     k.N = ctx->N;
     k.T = ctx->T;
@@ -721,7 +722,7 @@ void mag_destroy(mag_ctx *ctx)
         DevBuf *bufs[] = {&ctx->xy, &ctx->conn, &ctx->uknown, &ctx->uin, &ctx->fin, &ctx->scratch, &ctx->small,
                           &ctx->sK0, &ctx->sK1, &ctx->sV0, &ctx->sV1, &ctx->perm, &ctx->iperm, &ctx->xyP,
                           &ctx->maskP, &ctx->deg, &ctx->inc_off, &ctx->inc, &ctx->tile_deg, &ctx->tile_cnt,
-                          &ctx->tile_off, &ctx->ell, &ctx->hcnt, &ctx->hoffn, &ctx->hk0, &ctx->hk1, &ctx->halo_g,
+                          &ctx->tile_off, &ctx->ell, &ctx->hcnt, &ctx->hoffn, &ctx->hk0, &ctx->hk1, &ctx->halo_g, &ctx->halo_xy,
                           &ctx->tile_hcnt, &ctx->tile_hoff, &ctx->iface, &ctx->comm_pq, &ctx->comm_rr, &ctx->pk0, &ctx->pk1, &ctx->pv0, &ctx->pv1, &ctx->head,
                           &ctx->blk, &ctx->rowcnt, &ctx->seg_start, &ctx->bptr, &ctx->bcol, &ctx->kval, &ctx->ke,
                           &ctx->isfree, &ctx->fidx, &ctx->rcnt, &ctx->rowoff, &ctx->rp_ff, &ctx->col_ff,

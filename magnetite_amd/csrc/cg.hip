@@ -113,11 +113,13 @@ __global__ void __launch_bounds__(B) k_operator(const OpParams P)
     __shared__ double2 s_p[B];
     __shared__ double s_red[B / 64];
 
-    double beta = 0.0;
+    double beta = 0.0, alpha = 0.0;
     if (CG) {
         CgState *st = P.st;
         const long long k = st->iterA;
         const int was_done = st->done;
+        alpha = st->alpha_last;
+        const double rrh0 = st->rr_hist[0], rrh1 = st->rr_hist[1];
         const double rr = sum_partials<B>(P.partRR, P.nPart, s_red);
         if (was_done) return;
         const double cost = st->stop_mode == 1 ? fabs(rr) : sqrt(rr);
@@ -137,8 +139,22 @@ __global__ void __launch_bounds__(B) k_operator(const OpParams P)
                 st->iterB = k;
             }
         }
-        if (finished || broke || maxed) return;
-        const double rr_prev = (k == 0) ? rr : st->rr_hist[(k + 1) & 1];
+        if (finished || broke || maxed) {
+            if (!broke) {
+                for (int32_t t = P.t0 + blockIdx.x; t < P.t1; t += gridDim.x) {
+                    const int64_t nd = (int64_t)t * B + threadIdx.x;
+                    if (nd < P.N) {
+                        const double2 pp = P.pprev[nd];
+                        double2 xx = P.x[nd];
+                        xx.x += alpha * pp.x;
+                        xx.y += alpha * pp.y;
+                        P.x[nd] = xx;
+                    }
+                }
+            }
+            return;
+        }
+        const double rr_prev = (k == 0) ? rr : ((k & 1) ? rrh0 : rrh1);
         beta = rr / rr_prev;
     }
 
@@ -158,6 +174,10 @@ __global__ void __launch_bounds__(B) k_operator(const OpParams P)
                 pa.x = -r2.x + beta * pp.x;
                 pa.y = -r2.y + beta * pp.y;
                 P.pnew[node] = pa;
+                double2 xx = P.x[node];
+                xx.x += alpha * pp.x;
+                xx.y += alpha * pp.y;
+                P.x[node] = xx;
             } else {
                 pa = P.v[node];
                 if (P.masked) {
@@ -261,7 +281,7 @@ __global__ void __launch_bounds__(B) k_operator_lds(const OpParams P)
     // registers of the tile in flight
     int64_t node = 0;
     bool valid = false, hvalid = false;
-    double2 ca, a0, a1, hc, h0, h1;
+    double2 ca, a0, a1, xo, hc, h0, h1;
     uint8_t m = 3, hm = 0;
     int32_t deg = 0, nh = 0, hoff = 0;
     uint32_t w[kSlotRegs];
@@ -270,7 +290,7 @@ __global__ void __launch_bounds__(B) k_operator_lds(const OpParams P)
     auto load_tile = [&](int32_t t) {
         node = (int64_t)t * B + tid;
         valid = node < P.N;
-        ca = a0 = a1 = make_double2(0.0, 0.0);
+        ca = a0 = a1 = xo = make_double2(0.0, 0.0);
         m = 3;
         if (valid) {
             ca = P.xyP[node];
@@ -278,6 +298,7 @@ __global__ void __launch_bounds__(B) k_operator_lds(const OpParams P)
             if (CG) {
                 a0 = P.r[node];
                 a1 = P.pprev[node];
+                xo = P.x[node];
             } else {
                 a0 = P.v[node];
             }
@@ -288,12 +309,12 @@ __global__ void __launch_bounds__(B) k_operator_lds(const OpParams P)
         for (int k = 0; k < kSlotRegs; ++k) w[k] = k < deg ? ell[(int64_t)k * B] : 0xffffffffu;
         hoff = P.tile_hoff[t];
         nh = P.tile_hoff[t + 1] - hoff;
-        hvalid = tid < nh && !(P.ablate & 4);
+        hvalid = tid < nh;
         hc = h0 = h1 = make_double2(0.0, 0.0);
         hm = 0;
         if (hvalid) {
             const int32_t g = P.halo_g[hoff + tid];
-            hc = P.xyP[g];
+            hc = P.halo_xy[hoff + tid]; // static per-tile copy: coalesced, independent of the index load
             if (CG) {
                 h0 = P.r[g];
                 h1 = P.pprev[g];
@@ -304,19 +325,31 @@ __global__ void __launch_bounds__(B) k_operator_lds(const OpParams P)
         }
     };
 
+    // the whole CG state line is read before anything waits, together with the first tile's operands
+    CgState *st = P.st;
+    long long k = 0, max_iter = 0;
+    int was_done = 0, stop_mode = 0;
+    double rrh0 = 0.0, rrh1 = 0.0, target = 0.0, alpha = 0.0;
+    if (CG) {
+        k = st->iterA;
+        was_done = st->done;
+        rrh0 = st->rr_hist[0];
+        rrh1 = st->rr_hist[1];
+        target = st->target;
+        max_iter = st->max_iter;
+        stop_mode = st->stop_mode;
+        alpha = st->alpha_last;
+    }
     load_tile(P.t0 + blockIdx.x);
 
     double beta = 0.0;
     if (CG) {
-        CgState *st = P.st;
-        const long long k = st->iterA;
-        const int was_done = st->done;
         const double rr = sum_partials<B>(P.partRR, P.nPart, s_red);
         if (was_done) return;
-        const double cost = st->stop_mode == 1 ? fabs(rr) : sqrt(rr);
-        const bool finished = (k >= 1) && (cost <= st->target);
+        const double cost = stop_mode == 1 ? fabs(rr) : sqrt(rr);
+        const bool finished = (k >= 1) && (cost <= target);
         const bool broke = !(fabs(rr) <= 1.79769313486231570e308);
-        const bool maxed = k >= st->max_iter;
+        const bool maxed = k >= max_iter;
         if (blockIdx.x == 0 && tid == 0) {
             if (k >= 1 && k - 1 < P.hist_len) P.hist[k - 1] = cost;
             if (finished || broke || maxed) {
@@ -330,8 +363,23 @@ __global__ void __launch_bounds__(B) k_operator_lds(const OpParams P)
                 st->iterB = k;
             }
         }
-        if (finished || broke || maxed) return;
-        const double rr_prev = (k == 0) ? rr : st->rr_hist[(k + 1) & 1];
+        if (finished || broke || maxed) {
+            // x still lacks the last step alpha_{k-1} p_{k-1} (the update is folded into this kernel)
+            if (!broke) {
+                for (int32_t t = P.t0 + blockIdx.x; t < P.t1; t += gridDim.x) {
+                    const int64_t nd = (int64_t)t * B + tid;
+                    if (nd < P.N) {
+                        const double2 pp = P.pprev[nd];
+                        double2 xx = P.x[nd];
+                        xx.x += alpha * pp.x;
+                        xx.y += alpha * pp.y;
+                        P.x[nd] = xx;
+                    }
+                }
+            }
+            return;
+        }
+        const double rr_prev = (k == 0) ? rr : ((k & 1) ? rrh0 : rrh1);
         beta = rr / rr_prev;
     }
 
@@ -343,7 +391,13 @@ __global__ void __launch_bounds__(B) k_operator_lds(const OpParams P)
         if (CG) {
             pa.x = -a0.x + beta * a1.x;
             pa.y = -a0.y + beta * a1.y;
-            if (valid && (!(P.ablate & 2) || pa.x == 1.2345e300)) store2<WT>(P.pnew, P.N, node, pa);
+            if (valid) {
+                store2<WT>(P.pnew, P.N, node, pa);
+                // x += alpha_{k-1} p_{k-1}: argmin's param.scaled_add, one launch late, p_{k-1} is already here
+                xo.x += alpha * a1.x;
+                xo.y += alpha * a1.y;
+                store2<WT>(P.x, P.N, node, xo);
+            }
         } else {
             pa = a0;
             if (P.masked) {
@@ -390,12 +444,6 @@ __global__ void __launch_bounds__(B) k_operator_lds(const OpParams P)
         __syncthreads();
 
         double fx = 0.0, fy = 0.0;
-        if (P.ablate & 1) { // tuning only: no incident-element loop
-            fx = s_p[(tid + 1) & (B - 1)].x;
-            fy = s_xy[(tid + 1) & (B - 1)].y;
-#pragma unroll
-            for (int k = 0; k < kSlotRegs; ++k) fx += (double)(w[k] & 1u);
-        } else
 #pragma unroll
         for (int k = 0; k < kSlotRegs; ++k) {
             const uint32_t ww = w[k];
@@ -417,7 +465,7 @@ __global__ void __launch_bounds__(B) k_operator_lds(const OpParams P)
                 if (m & 2) fy = 0.0;
             }
             if (CG) {
-                if (!(P.ablate & 2) || fx == 1.2345e300) store2<WT>(P.q, P.N, node, make_double2(fx, fy));
+                store2<WT>(P.q, P.N, node, make_double2(fx, fy));
                 acc += pa.x * fx + pa.y * fy;
             } else {
                 P.y[node] = make_double2(fx, fy);
@@ -489,27 +537,23 @@ __global__ void __launch_bounds__(B) k_update(const UpdParams P)
     CgState *st = P.st;
     const int done = st->done;
     const long long k = st->iterB;
+    const double rrh0 = st->rr_hist[0], rrh1 = st->rr_hist[1];
     // first tile's operands are in flight while the p.q partials are reduced
     int32_t t = P.t0 + blockIdx.x;
     int64_t node = (int64_t)t * B + threadIdx.x;
-    double2 p = make_double2(0.0, 0.0), q = p, x = p, r = p;
+    double2 q = make_double2(0.0, 0.0), r = q;
     if (node < P.N) {
-        p = P.p[node];
         q = P.q[node];
-        x = P.x[node];
         r = P.r[node];
     }
     const double pq = sum_partials<B>(P.partPQ, P.nPart, s_red);
     if (done) return;
-    const double alpha = st->rr_hist[k & 1] / pq;
+    const double alpha = ((k & 1) ? rrh1 : rrh0) / pq;
     double acc = 0.0;
     for (;;) {
         if (node < P.N) {
-            x.x += alpha * p.x;
-            x.y += alpha * p.y;
             r.x += alpha * q.x;
             r.y += alpha * q.y;
-            store2<WT>(P.x, P.N, node, x);
             store2<WT>(P.r, P.N, node, r);
             acc += r.x * r.x + r.y * r.y;
         }
@@ -517,9 +561,7 @@ __global__ void __launch_bounds__(B) k_update(const UpdParams P)
         if (t >= P.t1) break;
         node = (int64_t)t * B + threadIdx.x;
         if (node < P.N) {
-            p = P.p[node];
             q = P.q[node];
-            x = P.x[node];
             r = P.r[node];
         }
     }
@@ -528,7 +570,7 @@ __global__ void __launch_bounds__(B) k_update(const UpdParams P)
         P.partRR[blockIdx.x] = tot;
         if (blockIdx.x == 0) {
             st->iterA = k + 1;
-            st->alpha_last = alpha;
+            st->alpha_last = alpha; // consumed by the next operator launch for x += alpha p
         }
     }
 }

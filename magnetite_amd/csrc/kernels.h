@@ -46,6 +46,8 @@ void halo_unique(const uint64_t *keys, const int32_t *head, const int32_t *blk, 
 void fill_ell16(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn, const int32_t *iperm,
                 const int32_t *tile_deg, const int64_t *tile_off, const int32_t *tile_hoff, const int32_t *halo_g,
                 int64_t N, int32_t B, int32_t T, uint32_t *ell, hipStream_t s);
+// halo_xy[i] = xyP[halo_g[i]]
+void halo_coords(const int32_t *halo_g, const double *xyP, int64_t n, double *halo_xy, hipStream_t s);
 // CSR pattern: 9 (row node, col node) pairs per element, key = row<<32 | col, val = 9e + 3a + b
 void csr_pairs(const int32_t *conn, int64_t E, uint64_t *keys, uint32_t *vals, hipStream_t s);
 // head[k] = 1 where sorted key k starts a new (row,col) block
@@ -129,15 +131,16 @@ struct OpParams {
     const uint32_t *ell16;   // LDS-halo variant (nullptr => gather variant): tile-local ids lb | lc<<16
     const int32_t *tile_hoff; // T+1 offsets into halo_g
     const int32_t *halo_g;   // per tile: sorted Hilbert ids of its halo nodes
+    const double2 *halo_xy;  // their coordinates, same layout (static copy)
     int32_t cap;             // LDS image capacity in nodes: B + max halo, <= kMaxLdsNodes
     int32_t wt;              // write-through (sc1) stores of pnew and q
-    int32_t ablate;          // tuning only: 1 skip element loop, 2 skip stores, 4 skip halo loads
     double c0, nu, h; // E t / (2 (1-nu^2)), nu, (1-nu)/2
     // CG mode
     const double2 *r;
     const double2 *pprev;
     double2 *pnew;
     double2 *q;
+    double2 *x; // x += alpha_{k-1} p_{k-1} happens here, where p_{k-1} is read anyway
     const double *partRR;
     double *partPQ;
     CgState *st;
@@ -154,9 +157,7 @@ struct UpdParams {
     int32_t T;
     int32_t nPart;
     int32_t t0, t1;
-    double2 *x;
     double2 *r;
-    const double2 *p;
     const double2 *q;
     const double *partPQ;
     double *partRR;

@@ -289,6 +289,18 @@ void halo_unique(const uint64_t *keys, const int32_t *head, const int32_t *blk, 
     k_halo_unique<<<blocks_for(n, 256), 256, 0, s>>>(keys, head, blk, n, halo_g, tile_hcnt);
 }
 
+__global__ void __launch_bounds__(256) k_halo_coords(const int32_t *halo_g, const double2 *xyP, int64_t n,
+                                                     double2 *halo_xy)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) halo_xy[i] = xyP[halo_g[i]];
+}
+
+void halo_coords(const int32_t *halo_g, const double *xyP, int64_t n, double *halo_xy, hipStream_t s)
+{
+    if (n > 0) k_halo_coords<<<blocks_for(n, 256), 256, 0, s>>>(halo_g, (const double2 *)xyP, n, (double2 *)halo_xy);
+}
+
 __device__ inline uint32_t local_id(int32_t g, int32_t base, int32_t B, const int32_t *hl, int32_t nh)
 {
     const uint32_t l = (uint32_t)(g - base);
