@@ -88,7 +88,12 @@ typedef struct mag_options {
     int32_t verbose;      /* 1: print the reference's "info:" phase lines to stdout        */
     int32_t op_variant;   /* 0 (default): LDS-halo operator when every tile fits LDS, else the
                              global-gather operator; 1: always the global-gather operator  */
-    int32_t reserved[4];
+    int32_t cg_variant;   /* 1 (default): one fused launch per CG iteration -- argmin's recurrences with the
+                             numerator of beta, |r_new|^2, expanded from exact dots of the previous iterate
+                             (r.r + 2 alpha r.q + alpha^2 q.q) so that one grid-wide reduction per iteration
+                             suffices; alpha, the stop test and the reported cost use the true r.r.
+                             0: two launches per iteration, argmin's recurrences to the letter              */
+    int32_t reserved[3];
 } mag_options;
 
 /* Borrowed view of the caller's flattened Vec<Node>/Vec<Element>/ModelMetadata

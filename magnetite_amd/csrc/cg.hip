@@ -719,6 +719,403 @@ void cg_setup(const double *partRR, int32_t nPart, int stop_mode, double tol, lo
     k_cg_setup<<<1, 256, 0, s>>>(partRR, nPart, stop_mode, tol, max_iter, st);
 }
 
+// ======================================================= fused CG iteration ===
+// ONE launch per CG iteration.  Launch j produces iterate j from iterate j-1 and the four dot products of
+// iterate j-1 (r.r, p.q, r.q, q.q, reduced from the previous launch's per-workgroup partials):
+//     alpha = r.r / p.q                      (argmin: rtr / p.dot(Ap), true dots)
+//     r_j = r + alpha q ; x_j = x + alpha p  (argmin: scaled_add)
+//     beta = (r.r + 2 alpha r.q + alpha^2 q.q) / r.r      <- |r_j|^2 one step ahead of its own reduction
+//     p_j = -r_j + beta p ; q_j = A p_j
+// The only departure from argmin's recurrences is the NUMERATOR of beta: |r_j|^2 expanded from exact dots of
+// iterate j-1 instead of a second grid-wide reduction.  The expansion restarts from the true r.r every launch, so
+// its error does not accumulate (one-step relative error ~ eps * |r_{j-1}|^2 / |r_j|^2); alpha, the stop test and
+// the reported cost all use the true r.r of the iterate, available one launch later.  Owner-computes as in
+// k_operator_lds; a tile recomputes r_j and p_j of its halo nodes from their previous record.
+template <int B>
+__device__ inline void block_sum4(double (&v)[4], double *s_red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] += __shfl_down(v[c], off);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s_red[c * (B / 64) + (threadIdx.x >> 6)] = v[c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < B / 64; ++i) t += s_red[c * (B / 64) + i];
+        v[c] = t;
+    }
+}
+
+template <int B, bool WT>
+__global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 smem[];
+    double2 *s_xy = smem;
+    double2 *s_p = smem + P.cap;
+    double *s_red = (double *)(smem + 2 * P.cap);
+    const int tid = threadIdx.x;
+
+    // ---- everything this launch reads first is issued before anything waits
+    FusedState *st = P.st;
+    const long long j = st->jslot[P.par];
+    const int was_done = st->done;
+    const double target = st->target;
+    const long long max_iter = st->max_iter;
+    const int stop_mode = st->stop_mode;
+
+    int64_t node = 0;
+    bool valid = false, hvalid = false;
+    double2 ca, ar, aq, ap, xo, hc, hr, hq, hp;
+    uint8_t m = 3;
+    int32_t deg = 0, nh = 0, hoff = 0, hg = 0;
+    uint32_t w[kSlotRegs];
+    const uint32_t *ell = nullptr;
+    auto load_tile = [&](int32_t t) {
+        const TileMeta tm = P.meta[t];
+        node = (int64_t)t * B + tid;
+        valid = node < P.N;
+        ca = ar = aq = ap = xo = make_double2(0.0, 0.0);
+        m = 3;
+        if (valid) {
+            const Rqp rec = P.in[node];
+            ar = rec.r;
+            aq = rec.q;
+            ap = rec.p;
+            xo = P.x[node];
+            ca = P.xyP[node];
+            m = P.maskP[node];
+        }
+        deg = tm.deg;
+        ell = P.ell16 + tm.ell_off + tid;
+#pragma unroll
+        for (int k = 0; k < kSlotRegs; ++k) w[k] = k < deg ? ell[(int64_t)k * B] : 0xffffffffu;
+        hoff = tm.hoff;
+        nh = tm.nh;
+        hvalid = tid < nh;
+        hc = hr = hq = hp = make_double2(0.0, 0.0);
+        if (hvalid) {
+            hg = P.halo_g[hoff + tid];
+            hc = P.halo_xy[hoff + tid];
+            const Rqp rec = P.in[hg];
+            hr = rec.r;
+            hq = rec.q;
+            hp = rec.p;
+        }
+    };
+    load_tile(P.t0 + blockIdx.x);
+
+    // ---- dots of iterate j-1
+    double S[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = tid; i < P.nPart; i += B) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) S[c] += P.part_in[c * P.part_stride_in + i];
+    }
+    block_sum4<B>(S, s_red);
+    if (was_done) return;
+    const double rr = S[0]; // |r_{j-1}|^2, exact
+    const double cost = stop_mode == 1 ? fabs(rr) : sqrt(rr);
+    const long long it_done = j - 1; // argmin iterations completed when this launch starts
+    const bool finished = (it_done >= 1) && (cost <= target);
+    const bool broke = !(fabs(rr) <= 1.79769313486231570e308);
+    const bool maxed = it_done >= max_iter;
+    if (blockIdx.x == 0 && tid == 0) {
+        if (it_done >= 1 && it_done - 1 < P.hist_len) P.hist[it_done - 1] = cost;
+        if (finished || broke || maxed) {
+            st->iterations = it_done < 0 ? 0 : it_done;
+            st->final_cost = cost;
+            st->converged = finished ? 1 : 0;
+            st->breakdown = broke ? 1 : 0;
+            st->done = 1;
+        } else {
+            st->jslot[P.par ^ 1] = j + 1;
+        }
+    }
+    if (finished || broke || maxed) return; // x, r of iterate j-1 are already in place
+    const double alpha = rr / S[1];
+    const double rr_next = rr + 2.0 * alpha * S[2] + alpha * alpha * S[3];
+    const double beta = rr_next / rr;
+
+    const double c0 = P.c0, nu = P.nu, h = P.h;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    int32_t t = P.t0 + blockIdx.x;
+    for (;;) {
+        // r_j, x_j, p_j of the owned node
+        double2 rn, pn;
+        rn.x = ar.x + alpha * aq.x;
+        rn.y = ar.y + alpha * aq.y;
+        pn.x = -rn.x + beta * ap.x;
+        pn.y = -rn.y + beta * ap.y;
+        xo.x += alpha * ap.x;
+        xo.y += alpha * ap.y;
+        __syncthreads(); // previous tile's readers are done with the LDS images
+        s_xy[tid] = ca;
+        s_p[tid] = pn;
+        if (hvalid) {
+            double2 hrn, hpn;
+            hrn.x = hr.x + alpha * hq.x;
+            hrn.y = hr.y + alpha * hq.y;
+            hpn.x = -hrn.x + beta * hp.x;
+            hpn.y = -hrn.y + beta * hp.y;
+            s_xy[B + tid] = hc;
+            s_p[B + tid] = hpn;
+        }
+        for (int32_t hh = tid + B; hh < nh; hh += B) { // more halo nodes than threads (rare)
+            const int32_t g = P.halo_g[hoff + hh];
+            const Rqp rec = P.in[g];
+            double2 hrn, hpn;
+            hrn.x = rec.r.x + alpha * rec.q.x;
+            hrn.y = rec.r.y + alpha * rec.q.y;
+            hpn.x = -hrn.x + beta * rec.p.x;
+            hpn.y = -hrn.y + beta * rec.p.y;
+            s_xy[B + hh] = P.halo_xy[hoff + hh];
+            s_p[B + hh] = hpn;
+        }
+        __syncthreads();
+
+        double fx = 0.0, fy = 0.0;
+#pragma unroll
+        for (int k = 0; k < kSlotRegs; ++k) {
+            const uint32_t ww = w[k];
+            if (ww != 0xffffffffu) {
+                const uint32_t lb = ww & 0xffffu, lc = ww >> 16;
+                corner_force(ca, pn, s_xy[lb], s_p[lb], s_xy[lc], s_p[lc], c0, nu, h, fx, fy);
+            }
+        }
+        for (int32_t k = kSlotRegs; k < deg; ++k) {
+            const uint32_t ww = ell[(int64_t)k * B];
+            if (ww != 0xffffffffu) {
+                const uint32_t lb = ww & 0xffffu, lc = ww >> 16;
+                corner_force(ca, pn, s_xy[lb], s_p[lb], s_xy[lc], s_p[lc], c0, nu, h, fx, fy);
+            }
+        }
+        if (valid) {
+            if (m & 1) fx = 0.0;
+            if (m & 2) fy = 0.0;
+            // 48-byte record, three 16-byte stores
+            store2<WT>((double2 *)P.out, 3 * P.N, 3 * node, rn);
+            store2<WT>((double2 *)P.out, 3 * P.N, 3 * node + 1, make_double2(fx, fy));
+            store2<WT>((double2 *)P.out, 3 * P.N, 3 * node + 2, pn);
+            store2<WT>(P.x, P.N, node, xo);
+            acc[0] += rn.x * rn.x + rn.y * rn.y;
+            acc[1] += pn.x * fx + pn.y * fy;
+            acc[2] += rn.x * fx + rn.y * fy;
+            acc[3] += fx * fx + fy * fy;
+        }
+        t += gridDim.x;
+        if (t >= P.t1) break;
+        load_tile(t);
+    }
+    // multi-GPU: records of interface nodes other ranks own are advanced locally (their q arrives by all-reduce)
+    for (int32_t k = blockIdx.x * B + tid; k < P.n_iface; k += gridDim.x * B) {
+        const int32_t g = P.iface[k];
+        if (g < P.own0 || g >= P.own1) {
+            const Rqp rec = P.in[g];
+            double2 rn, pn;
+            rn.x = rec.r.x + alpha * rec.q.x;
+            rn.y = rec.r.y + alpha * rec.q.y;
+            pn.x = -rn.x + beta * rec.p.x;
+            pn.y = -rn.y + beta * rec.p.y;
+            P.out[g].r = rn;
+            P.out[g].p = pn;
+        }
+    }
+    block_sum4<B>(acc, s_red);
+    if (tid == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) P.part_out[c * P.part_stride + blockIdx.x] = acc[c];
+    }
+}
+
+static size_t fused_lds_bytes(int32_t cap, int32_t B) { return (size_t)cap * 32 + (size_t)(B / 64) * 32 + 16; }
+
+int fused_grid(int32_t B, int32_t cap, int32_t tiles)
+{
+    int dev = 0, cus = 256, per_cu = 1;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const size_t lds = fused_lds_bytes(cap, B);
+    hipError_t e;
+    if (B == 256)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_fused<256, false>, 256, lds);
+    else if (B == 1024)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_fused<1024, false>, 1024, lds);
+    else
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_fused<512, false>, 512, lds);
+    if (e != hipSuccess || per_cu < 1) per_cu = 1;
+    long g = (long)per_cu * cus;
+    if (g > kMaxGrid) g = kMaxGrid;
+    if (g > tiles) g = tiles;
+    return g < 1 ? 1 : (int)g;
+}
+
+void fused_launch(const FusedParams &P, int32_t B, int32_t grid, hipStream_t s)
+{
+    const size_t lds = fused_lds_bytes(P.cap, B);
+#define MAG_FUSED(BB)                                     \
+    if (P.wt)                                             \
+        k_cg_fused<BB, true><<<grid, BB, lds, s>>>(P);    \
+    else                                                  \
+        k_cg_fused<BB, false><<<grid, BB, lds, s>>>(P);
+    if (B == 256) {
+        MAG_FUSED(256)
+    } else if (B == 1024) {
+        MAG_FUSED(1024)
+    } else {
+        MAG_FUSED(512)
+    }
+#undef MAG_FUSED
+}
+
+__global__ void __launch_bounds__(256) k_tile_meta(const int32_t *tile_deg, const int64_t *tile_off,
+                                                   const int32_t *tile_hoff, int32_t T, TileMeta *meta)
+{
+    const int32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    TileMeta m;
+    m.ell_off = tile_off[t];
+    m.deg = tile_deg[t];
+    m.hoff = tile_hoff[t];
+    m.nh = tile_hoff[t + 1] - tile_hoff[t];
+    m.pad = 0;
+    m.pad2 = 0;
+    meta[t] = m;
+}
+
+void tile_meta(const int32_t *tile_deg, const int64_t *tile_off, const int32_t *tile_hoff, int32_t T, TileMeta *meta,
+               hipStream_t s)
+{
+    k_tile_meta<<<(T + 255) / 256, 256, 0, s>>>(tile_deg, tile_off, tile_hoff, T, meta);
+}
+
+template <int B>
+__global__ void __launch_bounds__(B) k_fused_init(const double2 *bP, Rqp *in, Rqp *out, int64_t N, int32_t T,
+                                                  int32_t t0, int32_t t1, double *part, int32_t stride)
+{
+    __shared__ double s_red[B / 64];
+    double acc = 0.0;
+    const double2 z = make_double2(0.0, 0.0);
+    for (int32_t t = blockIdx.x; t < T; t += gridDim.x) {
+        const int64_t node = (int64_t)t * B + threadIdx.x;
+        if (node < N) {
+            const double2 b = bP[node];
+            Rqp rec;
+            rec.r = make_double2(-b.x, -b.y); // argmin init: r0 = -(b - A x0), x0 = 0
+            rec.q = z;
+            rec.p = z;
+            in[node] = rec;
+            out[node] = rec;
+            if (t >= t0 && t < t1) acc += b.x * b.x + b.y * b.y;
+        }
+    }
+    const double tot = block_sum<B>(acc, s_red);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = tot;
+        part[stride + blockIdx.x] = blockIdx.x == 0 ? 1.0 : 0.0; // "p.q" = 1: alpha finite, multiplies q = 0
+        part[2 * stride + blockIdx.x] = 0.0;
+        part[3 * stride + blockIdx.x] = 0.0;
+    }
+}
+
+void fused_init(const double2 *bP, Rqp *in, Rqp *out, int64_t N, int32_t B, int32_t T, int32_t t0, int32_t t1,
+                double *part, int32_t stride, int32_t grid, hipStream_t s)
+{
+    if (B == 256)
+        k_fused_init<256><<<grid, 256, 0, s>>>(bP, in, out, N, T, t0, t1, part, stride);
+    else if (B == 1024)
+        k_fused_init<1024><<<grid, 1024, 0, s>>>(bP, in, out, N, T, t0, t1, part, stride);
+    else
+        k_fused_init<512><<<grid, 512, 0, s>>>(bP, in, out, N, T, t0, t1, part, stride);
+}
+
+__global__ void __launch_bounds__(256) k_fused_setup(const double *part, int nPart, int32_t stride, int stop_mode,
+                                                     double tol, long long max_iter, FusedState *st)
+{
+    __shared__ double s_red[4];
+    (void)stride;
+    const double bb = sum_partials<256>(part, nPart, s_red);
+    if (threadIdx.x == 0) {
+        st->jslot[0] = 0;
+        st->jslot[1] = 0;
+        st->bb = bb;
+        st->tol = tol;
+        st->target = stop_mode == 2 ? tol * sqrt(bb) : tol;
+        st->stop_mode = stop_mode;
+        st->final_cost = stop_mode == 1 ? bb : sqrt(bb);
+        st->iterations = 0;
+        st->max_iter = max_iter;
+        st->breakdown = 0;
+        st->done = (bb == 0.0) ? 1 : 0; // b == 0: x = 0 (documented deviation)
+        st->converged = (bb == 0.0) ? 1 : 0;
+        if (bb == 0.0) st->final_cost = 0.0;
+    }
+}
+
+void fused_setup(const double *part, int32_t nPart, int32_t stride, int stop_mode, double tol, long long max_iter,
+                 FusedState *st, hipStream_t s)
+{
+    k_fused_setup<<<1, 256, 0, s>>>(part, nPart, stride, stop_mode, tol, max_iter, st);
+}
+
+__global__ void __launch_bounds__(256) k_fused_pack(const double *part, int nPart, int32_t stride, const Rqp *v,
+                                                    const int32_t *iface, int32_t n_iface, int32_t own0,
+                                                    int32_t own1, double *buf)
+{
+    __shared__ double s_red[16];
+    if (blockIdx.x == 0) {
+        double S[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = threadIdx.x; i < nPart; i += 256) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) S[c] += part[c * stride + i];
+        }
+        block_sum4<256>(S, s_red);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) buf[c] = S[c];
+        }
+    }
+    for (int32_t k = blockIdx.x * 256 + threadIdx.x; k < n_iface; k += gridDim.x * 256) {
+        const int32_t g = iface[k];
+        const bool mine = g >= own0 && g < own1;
+        const double2 val = mine ? v[g].q : make_double2(0.0, 0.0);
+        buf[4 + 2 * k] = val.x;
+        buf[5 + 2 * k] = val.y;
+    }
+}
+
+void fused_pack(const double *part, int nPart, int32_t stride, const Rqp *v, const int32_t *iface, int32_t n_iface,
+                int32_t own0, int32_t own1, double *buf, hipStream_t s)
+{
+    int grid = (n_iface + 255) / 256;
+    grid = grid < 1 ? 1 : (grid > 256 ? 256 : grid);
+    k_fused_pack<<<grid, 256, 0, s>>>(part, nPart, stride, v, iface, n_iface, own0, own1, buf);
+}
+
+__global__ void __launch_bounds__(256) k_fused_unpack(const double *buf, const int32_t *iface, int32_t n_iface,
+                                                      int32_t own0, int32_t own1, Rqp *v)
+{
+    for (int32_t k = blockIdx.x * 256 + threadIdx.x; k < n_iface; k += gridDim.x * 256) {
+        const int32_t g = iface[k];
+        if (g < own0 || g >= own1) v[g].q = make_double2(buf[4 + 2 * k], buf[5 + 2 * k]);
+    }
+}
+
+void fused_unpack(const double *buf, const int32_t *iface, int32_t n_iface, int32_t own0, int32_t own1, Rqp *v,
+                  hipStream_t s)
+{
+    if (n_iface <= 0) return;
+    int grid = (n_iface + 255) / 256;
+    grid = grid > 256 ? 256 : grid;
+    k_fused_unpack<<<grid, 256, 0, s>>>(buf, iface, n_iface, own0, own1, v);
+}
+
 // --------------------------------------------------- numbering helpers ---
 static inline int blocks_for(int64_t n, int threads)
 {

@@ -9,7 +9,7 @@
 
 namespace magk {
 
-constexpr int kMaxGrid = 1024;  // cap on workgroups of the CG kernels == number of dot partials
+constexpr int kMaxGrid = 1024;  // capacity of the dot-partial arrays == upper bound on workgroups of a CG kernel
 constexpr int kHilbertBits = 16;
 constexpr int kMaxLdsNodes = 2016; // (owned + halo) nodes per tile the LDS-halo operator stages: 32 B each < 64 KiB
 
@@ -164,6 +164,62 @@ struct UpdParams {
     CgState *st;
     int32_t wt;
 };
+
+// ---- fused single-launch CG iteration (cg_variant 1) ----
+// One record per node keeps what a neighbouring tile must read of it in one place: r, q = A p, p.
+struct Rqp {
+    double2 r, q, p;
+};
+struct TileMeta { // one 32-byte scalar load per tile instead of four dependent ones
+    int64_t ell_off;
+    int32_t deg, hoff, nh, pad;
+    int64_t pad2;
+};
+struct FusedState {
+    long long jslot[2]; // launch counter, read from slot[par], written to slot[par^1]
+    double target, final_cost, bb, tol;
+    long long iterations, max_iter;
+    int done, converged, breakdown, stop_mode;
+    double pad[6];
+};
+struct FusedParams {
+    int64_t N;
+    int32_t T, nPart, t0, t1, own0, own1, n_iface, cap, wt, par, hist_len, pad;
+    const double2 *xyP;
+    const uint8_t *maskP;
+    const TileMeta *meta;
+    const uint32_t *ell16;
+    const int32_t *halo_g;
+    const double2 *halo_xy;
+    const int32_t *iface;
+    double c0, nu, h;
+    const Rqp *in;
+    Rqp *out;
+    double2 *x;
+    const double *part_in; // 4 * nPart: sums of r.r, p.q, r.q, q.q of the previous iterate
+    double *part_out;      // 4 * gridDim
+    int32_t part_stride;    // entries per partial array in part_out
+    int32_t part_stride_in; // ... and in part_in (1 when the sums arrive all-reduced)
+    FusedState *st;
+    double *hist;
+};
+void tile_meta(const int32_t *tile_deg, const int64_t *tile_off, const int32_t *tile_hoff, int32_t T, TileMeta *meta,
+               hipStream_t s);
+// workgroups of the fused kernel: all co-resident (occupancy query x CUs), so the launch is one persistent round --
+// measured best on MI355X (fewer, fatter workgroups also mean fewer dot partials for every workgroup to reduce)
+int fused_grid(int32_t B, int32_t cap, int32_t tiles);
+void fused_launch(const FusedParams &P, int32_t B, int32_t grid, hipStream_t s);
+// in[node] = {-b, 0, 0}; part[0..] = {b.b partials over owned tiles, 1/grid, 0, 0} so that launch 0 gets
+// alpha finite, beta = 1
+void fused_init(const double2 *bP, Rqp *in, Rqp *out, int64_t N, int32_t B, int32_t T, int32_t t0, int32_t t1,
+                double *part, int32_t stride, int32_t grid, hipStream_t s);
+void fused_setup(const double *part, int32_t nPart, int32_t stride, int stop_mode, double tol, long long max_iter,
+                 FusedState *st, hipStream_t s);
+// multi-GPU: buf = [4 dot sums | q on owned interface nodes]; unpack writes q of the others into out[g].q
+void fused_pack(const double *part, int nPart, int32_t stride, const Rqp *v, const int32_t *iface, int32_t n_iface,
+                int32_t own0, int32_t own1, double *buf, hipStream_t s);
+void fused_unpack(const double *buf, const int32_t *iface, int32_t n_iface, int32_t own0, int32_t own1, Rqp *v,
+                  hipStream_t s);
 
 int cg_grid(int32_t T);
 // operator kernel, B in {256,512,1024}; cg_mode: p = -r + beta*pprev fused, writes pnew, q, partPQ

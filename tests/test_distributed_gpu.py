@@ -10,19 +10,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
-def launch(nproc, mode, port):
+def launch(nproc, mode, port, variant=1):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER, "--mode", mode]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER, "--mode", mode, "--variant", str(variant)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
 
 
-@pytest.mark.parametrize("nproc", [2, 3])
-def test_ranks_sharing_one_gpu_through_gloo(built, nproc):
-    r = launch(nproc, "callback", 29540 + nproc)
+@pytest.mark.parametrize("nproc,variant", [(2, 1), (3, 1), (2, 0)])
+def test_ranks_sharing_one_gpu_through_gloo(built, nproc, variant):
+    r = launch(nproc, "callback", 29540 + nproc + 10 * variant, variant)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
 
 
-def test_rccl_single_rank_communicator(built):
-    r = subprocess.run([sys.executable, WORKER, "--mode", "rccl1"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+@pytest.mark.parametrize("variant", [1, 0])
+def test_rccl_single_rank_communicator(built, variant):
+    r = subprocess.run([sys.executable, WORKER, "--mode", "rccl1", "--variant", str(variant)], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]

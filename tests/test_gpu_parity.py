@@ -92,11 +92,12 @@ def test_matrix_free_operator_matches_csr(ctx, name):
 
 
 @pytest.mark.parametrize("name", list(PROBLEMS))
-@pytest.mark.parametrize("assemble", [1, 0])
-def test_full_solve_parity(built, name, assemble):
+@pytest.mark.parametrize("assemble,variant", [(1, 1), (0, 1), (1, 0)])
+def test_full_solve_parity(built, name, assemble, variant):
+    """variant 1: one fused launch per iteration (default); 0: two launches, argmin's recurrences to the letter."""
     p = PROBLEMS[name]
     ref = oracle_run(p, hist_len=16)
-    with Context(device=0, history_len=16, assemble_csr=assemble) as c:
+    with Context(device=0, history_len=16, assemble_csr=assemble, cg_variant=variant) as c:
         out = c.solve(p)
         hist = c.history(min(16, out["iterations"]))
     assert out["converged"] == 1
@@ -125,7 +126,8 @@ def test_full_solve_parity(built, name, assemble):
 def test_stop_modes_and_eager(built):
     p = PROBLEMS["hole_perturbed"]
     for kw in (dict(stop_mode=MAG_STOP_RNORM_SQ), dict(stop_mode=MAG_STOP_REL, tol=1e-10),
-               dict(use_graph=0), dict(check_every=2), dict(tile_nodes=256), dict(tile_nodes=1024)):
+               dict(use_graph=0), dict(check_every=2), dict(tile_nodes=256), dict(tile_nodes=1024),
+               dict(cg_variant=0, use_graph=0), dict(cg_variant=0, tile_nodes=256, stop_mode=MAG_STOP_RNORM_SQ)):
         okw = {}
         if "stop_mode" in kw:
             okw = dict(stop_mode=kw["stop_mode"], tol=kw.get("tol", 1e-4))
