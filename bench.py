@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--tile", type=int, default=512)
     ap.add_argument("--check-every", type=int, default=64)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cg-variant", type=int, default=1, help="1: one fused launch per CG iteration, 0: two launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-iters", type=int, default=150)
     ap.add_argument("--op-reps", type=int, default=400)
@@ -107,7 +108,7 @@ def main():
     E, N = prob.mesh.num_elements, prob.mesh.num_nodes
 
     ctx = Context(device=local_rank, stop_mode=stop_mode, tol=args.tol, tile_nodes=args.tile,
-                  check_every=args.check_every, use_graph=0 if args.no_graph else 1)
+                  check_every=args.check_every, use_graph=0 if args.no_graph else 1, cg_variant=args.cg_variant)
     if world > 1:
         ctx.init_rccl_from_torch(dist, rank, world)
     ctx.upload_problem(prob)  # inputs resident in HBM before the timed region
@@ -131,7 +132,9 @@ def main():
         elapsed = float(t.item())
 
     st = ctx.stats()
-    ms_op = ctx.time_operator(args.op_reps)  # HIP events on the library's stream around op_reps launches
+    # HIP events on the library's own stream around op_reps back-to-back launches (mag_time_operator / mag_time_spmv)
+    ms_op = ctx.time_operator(args.op_reps)   # the CG iteration kernel (dominant: one launch per iteration)
+    ms_spmv = ctx.time_spmv(args.op_reps)     # the plain matrix-free SpMV y = M K M v
     u, _, _ = ctx.download()
 
     if rank == 0:
@@ -139,9 +142,19 @@ def main():
         ms_step = elapsed * 1e3 / args.steps
         Eloc, Nloc = E / world, N / world  # per-GPU share the operator kernel processes per launch
         spmv_bytes = 12.0 * Eloc + 50.0 * Nloc          # matrix-free SpMV
-        iter_bytes = 12.0 * Eloc + 242.0 * Nloc         # full CG iteration
-        achieved = spmv_bytes / (ms_op * 1e-3) / 1e9
+        iter_bytes = 12.0 * Eloc + 242.0 * Nloc         # full CG iteration (SpMV + 2 dots + 3 axpy)
+        fused = args.cg_variant == 1
+        kernel_bytes = iter_bytes if fused else spmv_bytes
+        achieved = kernel_bytes / (ms_op * 1e-3) / 1e9
+        spmv_gbs = spmv_bytes / (ms_spmv * 1e-3) / 1e9
         asm_ms = st["ms_element"] + st["ms_assemble"] + st["ms_bc"]
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+        if os.path.exists(pmc):  # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md)
+            pj = json.load(open(pmc))
+            key = f"{args.workload}:tile{args.tile}:variant{args.cg_variant}"
+            if key in pj:
+                traffic, traffic_src = pj[key]["hbm_bytes_per_launch"], "profiles/r01_pmc_summary.json:" + key
         out = {
             "metric": "elements/sec assembly + CG iters/sec (achieved HBM GB/s), 1M-tri mesh",
             "value": E * args.steps / elapsed, "unit": "elements/s",
@@ -149,11 +162,20 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}, {E} triangles, {N} nodes, left edge fixed, "
                                    f"right edge ux=delta; full solver::run per step; CG stop={args.stop} tol={args.tol:g}",
-                       "elements": E, "nodes": N, "tile_nodes": args.tile, "cg_stop": args.stop, "cg_tol": args.tol,
+                       "elements": E, "nodes": N, "tile_nodes": args.tile, "cg_variant": args.cg_variant, "cg_stop": args.stop, "cg_tol": args.tol,
                        "parallelism": f"strips{world}" if world > 1 else "single"},
-            "roofline": {"bound": "hbm", "kernel": "k_operator<%d,true> (matrix-free SpMV fused with p-update and p.q)" % args.tile,
+            "roofline": {"bound": "hbm",
+                         "kernel": ("k_cg_fused_dma<%d> (whole CG iteration in one launch: r,x,p updates + matrix-free "
+                                    "SpMV + 4 dot partials)" % args.tile) if fused else
+                                   ("k_operator_lds<%d> (matrix-free SpMV fused with p and x updates, p.q)" % args.tile),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "bytes_per_launch": spmv_bytes, "us_per_launch": ms_op * 1e3},
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "bytes_per_launch": kernel_bytes,
+                         "bytes_formula": "12E+242N (full CG iteration, SURVEY 8d)" if fused else "12E+50N (SpMV, SURVEY 8d)",
+                         "us_per_launch": ms_op * 1e3},
+            "spmv": {"kernel": "k_operator_lds<%d,false> (plain matrix-free SpMV)" % args.tile, "achieved": spmv_gbs,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
+                     "bytes_per_launch": spmv_bytes, "us_per_launch": ms_spmv * 1e3},
             "cg_iterations": iters, "cg_converged": int(st["converged"]), "cg_final_cost": st["final_cost"],
             "cg_iters_per_sec": iters / (st["ms_cg"] * 1e-3) if st["ms_cg"] > 0 else None,
             "cg_iteration_gbps": iter_bytes * iters / (st["ms_cg"] * 1e-3) / 1e9 if st["ms_cg"] > 0 else None,

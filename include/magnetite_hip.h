@@ -186,9 +186,12 @@ int mag_reduce_system(mag_ctx *ctx, int64_t *n_free, int64_t *nnz_ff, int32_t *r
  * (x, y: host, 2N, caller's DOF numbering).  masked != 0 applies M K M with M
  * zeroing prescribed-displacement DOFs (that is K_ff embedded in full length). */
 int mag_apply_operator(mag_ctx *ctx, const double *x, double *y, int32_t masked);
-/* Bench helper: `reps` back-to-back launches of the operator kernel on the context's
- * stream between two HIP events; *ms_per_launch = elapsed / reps. */
+/* Bench helper: `reps` back-to-back launches of the CG iteration kernel (cg_variant 1: the fused
+ * iteration kernel; 0: the operator kernel of the two-launch iteration) on the context's stream
+ * between two HIP events; *ms_per_launch = elapsed / reps. */
 int mag_time_operator(mag_ctx *ctx, int32_t reps, double *ms_per_launch);
+/* The same for the plain matrix-free SpMV y = M K M v (no CG update fused in). */
+int mag_time_spmv(mag_ctx *ctx, int32_t reps, double *ms_per_launch);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ------------------- */
 #define MAG_UNIQUE_ID_BYTES 128

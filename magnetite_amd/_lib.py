@@ -23,7 +23,7 @@ MAG_UNIQUE_ID_BYTES = 128
 SYMBOLS = [
     "mag_version", "mag_default_options", "mag_create", "mag_destroy", "mag_last_error", "mag_solve",
     "mag_upload", "mag_run", "mag_download", "mag_get_stats", "mag_get_history", "mag_compute_element_area",
-    "mag_element_stiffness", "mag_assemble_csr", "mag_reduce_system", "mag_apply_operator", "mag_time_operator",
+    "mag_element_stiffness", "mag_assemble_csr", "mag_reduce_system", "mag_apply_operator", "mag_time_operator", "mag_time_spmv",
     "mag_comm_get_unique_id", "mag_comm_init_rccl", "mag_comm_init_callback",
 ]
 
@@ -103,6 +103,7 @@ def lib():
     L.mag_reduce_system.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), ip, ip, dp, dp]
     L.mag_apply_operator.argtypes = [vp, dp, dp, C.c_int32]
     L.mag_time_operator.argtypes = [vp, C.c_int32, dp]
+    L.mag_time_spmv.argtypes = [vp, C.c_int32, dp]
     L.mag_comm_get_unique_id.argtypes = [vp]
     L.mag_comm_init_rccl.argtypes = [vp, vp, C.c_int32, C.c_int32]
     L.mag_comm_init_callback.argtypes = [vp, C.c_int32, C.c_int32, ALLREDUCE_FN, vp]

@@ -81,7 +81,7 @@ struct mag_ctx {
     // tile-local numbering for the LDS-halo operator
     bool use_lds = false;
     int tune_wt = 1;       // two-launch variant: write-through (sc1) stores of p, q, x, r
-    int tune_wt_fused = 0; // fused variant: 16-byte write-through pieces of 48-byte records measured slower
+    int tune_wt_fused = 1; // fused variant (LDS-DMA kernel stores linear 1-KiB pieces; the AoS kernel ignores it)
     int32_t cap = 0, max_halo = 0;
     int64_t halo_total = 0;
     DevBuf hcnt, hoffn, hk0, hk1, halo_g, halo_xy, tile_hcnt, tile_hoff;
@@ -1282,6 +1282,24 @@ int mag_time_operator(mag_ctx *ctx, int32_t reps, double *ms_per_launch)
     }
     HIPCHK(hipEventRecord(ctx->ev[9], s));
     HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    *ms_per_launch = ev_ms(ctx->ev[8], ctx->ev[9]) / reps;
+    return MAG_OK;
+}
+
+int mag_time_spmv(mag_ctx *ctx, int32_t reps, double *ms_per_launch)
+{
+    if (int rc = enter(ctx)) return rc;
+    if (!ctx->have_order || !ctx->tmpP.p) return fail(ctx, MAG_ERR_STATE, "mag_time_spmv needs a completed mag_run");
+    if (reps < 1 || !ms_per_launch) return fail(ctx, MAG_ERR_BAD_ARGS, "reps < 1 or null output");
+    hipStream_t s = ctx->stream;
+    // y = M K M v, nothing fused: the SpMV proper (tmpP holds a leftover vector of the run, q is free)
+    for (int i = 0; i < 3; ++i)
+        if (int rc = apply_plain(ctx, ctx->tmpP.as<double>(), ctx->q.as<double>(), 1)) return rc;
+    HIPCHK(hipEventRecord(ctx->ev[8], s));
+    for (int i = 0; i < reps; ++i)
+        if (int rc = apply_plain(ctx, ctx->tmpP.as<double>(), ctx->q.as<double>(), 1)) return rc;
+    HIPCHK(hipEventRecord(ctx->ev[9], s));
     HIPCHK(hipStreamSynchronize(s));
     *ms_per_launch = ev_ms(ctx->ev[8], ctx->ev[9]) / reps;
     return MAG_OK;

@@ -21,6 +21,7 @@
 // order from <= kMaxGrid per-workgroup partials by every workgroup of the
 // NEXT launch (the kernel boundary is the grid-wide sync), so results are
 // bitwise reproducible run to run.
+#include <cstdlib>
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -934,16 +935,240 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
     }
 }
 
-static size_t fused_lds_bytes(int32_t cap, int32_t B) { return (size_t)cap * 32 + (size_t)(B / 64) * 32 + 16; }
+template <int B, bool WT>
+__global__ void __launch_bounds__(B) k_cg_fused_dma(const FusedParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 smem[];
+    double2 *s_xy = smem;
+    double2 *s_p = smem + P.cap;
+    double *s_red = (double *)(smem + 2 * P.cap);
+    // LDS-DMA staging (global_load_lds_dwordx4: HBM -> LDS without passing through VGPRs, so nothing of the tile is
+    // held in registers while the dots are reduced).  A wave moves its 64 records (3 KiB) as three fully coalesced
+    // 1-KiB pieces into a wave-private stage and each lane picks its 48-byte record out of LDS (stride 3 x 16 B:
+    // conflict-free); a per-lane 48-byte-stride global access streams ~20 % slower.  Halo records are gathered by
+    // DMA too (per-lane source address, lane-linear destination).
+    double2 *s_stage_all = (double2 *)(s_red + 4 * (B / 64));
+    double2 *s_stage = s_stage_all + (threadIdx.x >> 6) * 192;
+    double2 *s_hr = s_stage_all + 3 * B, *s_hq = s_hr + B, *s_hp = s_hq + B;
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void glb_void;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const double2 *in2 = (const double2 *)P.in;
+    double2 *out2 = (double2 *)P.out;
+    const int64_t n3 = 3 * P.N;
+
+    // ---- everything this launch reads first is issued before anything waits
+    FusedState *st = P.st;
+    const long long j = st->jslot[P.par];
+    const int was_done = st->done;
+    const double target = st->target;
+    const long long max_iter = st->max_iter;
+    const int stop_mode = st->stop_mode;
+
+    int64_t node = 0, wbase = 0;
+    bool valid = false, hvalid = false;
+    double2 xo;
+    uint8_t m = 3;
+    int32_t deg = 0, nh = 0, hoff = 0;
+    uint32_t w[kSlotRegs];
+    const uint32_t *ell = nullptr;
+    // callers guarantee that no wave still reads s_xy / the stages of the previous tile (barrier before the call)
+    auto load_tile = [&](int32_t t) {
+        const TileMeta tm = P.meta[t];
+        node = (int64_t)t * B + tid;
+        wbase = 3 * ((int64_t)t * B + (tid & ~63));
+        valid = node < P.N;
+        hoff = tm.hoff;
+        nh = tm.nh;
+        hvalid = tid < nh;
+        int32_t hg = 0;
+        if (hvalid) hg = P.halo_g[hoff + tid];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            if (wbase + 64 * c + lane < n3)
+                __builtin_amdgcn_global_load_lds((glb_void *)(in2 + wbase + 64 * c + lane), (lds_void *)(s_stage + 64 * c),
+                                                 16, 0, 0);
+        if (valid)
+            __builtin_amdgcn_global_load_lds((glb_void *)(P.xyP + node), (lds_void *)(s_xy + wv * 64), 16, 0, 0);
+        xo = make_double2(0.0, 0.0);
+        m = 3;
+        if (valid) {
+            xo = P.x[node];
+            m = P.maskP[node];
+        }
+        deg = tm.deg;
+        ell = P.ell16 + tm.ell_off + tid;
+#pragma unroll
+        for (int k = 0; k < kSlotRegs; ++k) w[k] = k < deg ? ell[(int64_t)k * B] : 0xffffffffu;
+        if (hvalid) {
+            __builtin_amdgcn_global_load_lds((glb_void *)(P.halo_xy + hoff + tid), (lds_void *)(s_xy + B + wv * 64), 16, 0, 0);
+            const double2 *src = (const double2 *)(P.in + hg);
+            __builtin_amdgcn_global_load_lds((glb_void *)(src), (lds_void *)(s_hr + wv * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void *)(src + 1), (lds_void *)(s_hq + wv * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void *)(src + 2), (lds_void *)(s_hp + wv * 64), 16, 0, 0);
+        }
+    };
+    load_tile(P.t0 + blockIdx.x);
+
+    // ---- dots of iterate j-1
+    double S[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = tid; i < P.nPart; i += B) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) S[c] += P.part_in[c * P.part_stride_in + i];
+    }
+    block_sum4<B>(S, s_red);
+    if (was_done) return;
+    const double rr = S[0]; // |r_{j-1}|^2, exact
+    const double cost = stop_mode == 1 ? fabs(rr) : sqrt(rr);
+    const long long it_done = j - 1; // argmin iterations completed when this launch starts
+    const bool finished = (it_done >= 1) && (cost <= target);
+    const bool broke = !(fabs(rr) <= 1.79769313486231570e308);
+    const bool maxed = it_done >= max_iter;
+    if (blockIdx.x == 0 && tid == 0) {
+        if (it_done >= 1 && it_done - 1 < P.hist_len) P.hist[it_done - 1] = cost;
+        if (finished || broke || maxed) {
+            st->iterations = it_done < 0 ? 0 : it_done;
+            st->final_cost = cost;
+            st->converged = finished ? 1 : 0;
+            st->breakdown = broke ? 1 : 0;
+            st->done = 1;
+        } else {
+            st->jslot[P.par ^ 1] = j + 1;
+        }
+    }
+    if (finished || broke || maxed) return; // x, r of iterate j-1 are already in place
+    const double alpha = rr / S[1];
+    const double rr_next = rr + 2.0 * alpha * S[2] + alpha * alpha * S[3];
+    const double beta = rr_next / rr;
+
+    const double c0 = P.c0, nu = P.nu, h = P.h;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    int32_t t = P.t0 + blockIdx.x;
+    for (;;) {
+        // this wave's DMA has landed: pick the lane's record (r, q, p of iterate j-1) and coordinates out of LDS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const double2 ar = s_stage[3 * lane], aq = s_stage[3 * lane + 1], ap = s_stage[3 * lane + 2];
+        const double2 ca = s_xy[tid];
+        // r_j, x_j, p_j of the owned node
+        double2 rn, pn;
+        rn.x = ar.x + alpha * aq.x;
+        rn.y = ar.y + alpha * aq.y;
+        pn.x = -rn.x + beta * ap.x;
+        pn.y = -rn.y + beta * ap.y;
+        xo.x += alpha * ap.x;
+        xo.y += alpha * ap.y;
+        s_p[tid] = pn;
+        if (hvalid) {
+            const double2 hr = s_hr[tid], hq = s_hq[tid], hp = s_hp[tid];
+            double2 hrn, hpn;
+            hrn.x = hr.x + alpha * hq.x;
+            hrn.y = hr.y + alpha * hq.y;
+            hpn.x = -hrn.x + beta * hp.x;
+            hpn.y = -hrn.y + beta * hp.y;
+            s_p[B + tid] = hpn;
+        }
+        for (int32_t hh = tid + B; hh < nh; hh += B) { // more halo nodes than threads (rare)
+            const int32_t g = P.halo_g[hoff + hh];
+            const Rqp rec = P.in[g];
+            double2 hrn, hpn;
+            hrn.x = rec.r.x + alpha * rec.q.x;
+            hrn.y = rec.r.y + alpha * rec.q.y;
+            hpn.x = -hrn.x + beta * rec.p.x;
+            hpn.y = -hrn.y + beta * rec.p.y;
+            s_xy[B + hh] = P.halo_xy[hoff + hh];
+            s_p[B + hh] = hpn;
+        }
+        __syncthreads();
+
+        double fx = 0.0, fy = 0.0;
+#pragma unroll
+        for (int k = 0; k < kSlotRegs; ++k) {
+            const uint32_t ww = w[k];
+            if (ww != 0xffffffffu) {
+                const uint32_t lb = ww & 0xffffu, lc = ww >> 16;
+                corner_force(ca, pn, s_xy[lb], s_p[lb], s_xy[lc], s_p[lc], c0, nu, h, fx, fy);
+            }
+        }
+        for (int32_t k = kSlotRegs; k < deg; ++k) {
+            const uint32_t ww = ell[(int64_t)k * B];
+            if (ww != 0xffffffffu) {
+                const uint32_t lb = ww & 0xffffu, lc = ww >> 16;
+                corner_force(ca, pn, s_xy[lb], s_p[lb], s_xy[lc], s_p[lc], c0, nu, h, fx, fy);
+            }
+        }
+        if (m & 1) fx = 0.0;
+        if (m & 2) fy = 0.0;
+        // record of iterate j -> wave stage -> three coalesced 1-KiB stores
+        s_stage[3 * lane] = rn;
+        s_stage[3 * lane + 1] = make_double2(fx, fy);
+        s_stage[3 * lane + 2] = pn;
+        __builtin_amdgcn_wave_barrier();
+        {
+            const double2 o0 = s_stage[lane], o1 = s_stage[64 + lane], o2 = s_stage[128 + lane];
+            if (wbase + lane < n3) store2<WT>(out2, n3, wbase + lane, o0);
+            if (wbase + 64 + lane < n3) store2<WT>(out2, n3, wbase + 64 + lane, o1);
+            if (wbase + 128 + lane < n3) store2<WT>(out2, n3, wbase + 128 + lane, o2);
+        }
+        if (valid) {
+            store2<WT>(P.x, P.N, node, xo);
+            acc[0] += rn.x * rn.x + rn.y * rn.y;
+            acc[1] += pn.x * fx + pn.y * fy;
+            acc[2] += rn.x * fx + rn.y * fy;
+            acc[3] += fx * fx + fy * fy;
+        }
+        t += gridDim.x;
+        if (t >= P.t1) break;
+        __syncthreads(); // every wave is done with this tile's LDS images before the next tile's DMA overwrites them
+        load_tile(t);
+    }
+    // multi-GPU: records of interface nodes other ranks own are advanced locally (their q arrives by all-reduce)
+    for (int32_t k = blockIdx.x * B + tid; k < P.n_iface; k += gridDim.x * B) {
+        const int32_t g = P.iface[k];
+        if (g < P.own0 || g >= P.own1) {
+            const Rqp rec = P.in[g];
+            double2 rn, pn;
+            rn.x = rec.r.x + alpha * rec.q.x;
+            rn.y = rec.r.y + alpha * rec.q.y;
+            pn.x = -rn.x + beta * rec.p.x;
+            pn.y = -rn.y + beta * rec.p.y;
+            P.out[g].r = rn;
+            P.out[g].p = pn;
+        }
+    }
+    block_sum4<B>(acc, s_red);
+    if (tid == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) P.part_out[c * P.part_stride + blockIdx.x] = acc[c];
+    }
+}
+
+static size_t fused_lds_bytes(int32_t cap, int32_t B, bool dma)
+{
+    return (size_t)cap * 32 + (size_t)(B / 64) * 32 + 16 + (dma ? (size_t)B * 96 : 0);
+}
+
+static bool fused_dma()
+{
+    static const int v = [] { const char *e = getenv("MAG_TUNE_DMA"); return e ? atoi(e) : 1; }();
+    return v != 0;
+}
 
 int fused_grid(int32_t B, int32_t cap, int32_t tiles)
 {
     int dev = 0, cus = 256, per_cu = 1;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const size_t lds = fused_lds_bytes(cap, B);
+    const bool dma = fused_dma();
+    const size_t lds = fused_lds_bytes(cap, B, dma);
     hipError_t e;
-    if (B == 256)
+    if (dma) {
+        if (B == 256)
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_fused_dma<256, false>, 256, lds);
+        else
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_fused_dma<512, false>, 512, lds);
+    } else if (B == 256)
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_fused<256, false>, 256, lds);
     else if (B == 1024)
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_fused<1024, false>, 1024, lds);
@@ -958,12 +1183,21 @@ int fused_grid(int32_t B, int32_t cap, int32_t tiles)
 
 void fused_launch(const FusedParams &P, int32_t B, int32_t grid, hipStream_t s)
 {
-    const size_t lds = fused_lds_bytes(P.cap, B);
-#define MAG_FUSED(BB)                                     \
-    if (P.wt)                                             \
-        k_cg_fused<BB, true><<<grid, BB, lds, s>>>(P);    \
-    else                                                  \
-        k_cg_fused<BB, false><<<grid, BB, lds, s>>>(P);
+    const bool dma = fused_dma() && B != 1024;
+    const size_t lds = fused_lds_bytes(P.cap, B, dma);
+    if (dma) {
+        if (B == 256 && P.wt)
+            k_cg_fused_dma<256, true><<<grid, 256, lds, s>>>(P);
+        else if (B == 256)
+            k_cg_fused_dma<256, false><<<grid, 256, lds, s>>>(P);
+        else if (P.wt)
+            k_cg_fused_dma<512, true><<<grid, 512, lds, s>>>(P);
+        else
+            k_cg_fused_dma<512, false><<<grid, 512, lds, s>>>(P);
+        return;
+    }
+    // per-lane 48-byte-stride records: 16-byte write-through pieces measured slower than plain stores here
+#define MAG_FUSED(BB) k_cg_fused<BB, false><<<grid, BB, lds, s>>>(P);
     if (B == 256) {
         MAG_FUSED(256)
     } else if (B == 1024) {

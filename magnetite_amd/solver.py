@@ -232,6 +232,11 @@ class Context:
         self._check(self._L.mag_time_operator(self._h, reps, C.byref(ms)))
         return ms.value
 
+    def time_spmv(self, reps=200):
+        ms = C.c_double(0.0)
+        self._check(self._L.mag_time_spmv(self._h, reps, C.byref(ms)))
+        return ms.value
+
 
 def flatten(nodes, elements):
     """Vec<Node>/Vec<Element> -> SoA (what the Rust shim does before the extern "C" call).
