@@ -95,6 +95,7 @@ struct mag_ctx {
     DevBuf pk0, pk1, pv0, pv1, head, blk, rowcnt, seg_start, bptr, bcol, kval, ke;
     // reduced system scratch
     DevBuf isfree, fidx, rcnt, rowoff, rp_ff, col_ff, val_ff, b_ff, rp_full, col_full;
+    int64_t nf = 0, nz_ff = 0;
 
     // CG (Hilbert numbering)
     DevBuf x, r, p0, p1, q, bP, tmpP, partRR, partPQ, state, hist;
@@ -205,7 +206,7 @@ int ensure_order(mag_ctx *ctx)
     HIPCHK(ctx->sK1.reserve(4 * nmax));
     HIPCHK(ctx->sV0.reserve(4 * nmax));
     HIPCHK(ctx->sV1.reserve(4 * nmax));
-    HIPCHK(ctx->small.reserve(8 * (4 * 256 + 4) + 64));
+    HIPCHK(ctx->small.reserve(8 * (4 * 256 + 4) + 64)); // bbox partials, bbox, {error flag, known count}
     HIPCHK(ctx->perm.reserve(4 * (size_t)N));
     HIPCHK(ctx->iperm.reserve(4 * (size_t)N));
     HIPCHK(ctx->xyP.reserve(16 * (size_t)N));
@@ -227,11 +228,11 @@ int ensure_order(mag_ctx *ctx)
                           ctx->sV1.as<uint32_t>(), (size_t)N, 2 * magk::kHilbertBits))
         return rc;
     HIPCHK(hipMemcpyAsync(ctx->perm.p, ctx->sV1.p, 4 * (size_t)N, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemsetAsync(errflag, 0, 8, s)); // {error flag, prescribed-displacement count}
     magk::apply_order(ctx->perm.as<uint32_t>(), ctx->xy.as<double>(), ctx->uknown.as<uint8_t>(), N,
-                      ctx->iperm.as<int32_t>(), ctx->xyP.as<double>(), ctx->maskP.as<uint8_t>(), s);
+                      ctx->iperm.as<int32_t>(), ctx->xyP.as<double>(), ctx->maskP.as<uint8_t>(), errflag + 1, s);
 
     HIPCHK(hipMemsetAsync(ctx->deg.p, 0, 4 * ((size_t)N + 1), s));
-    HIPCHK(hipMemsetAsync(errflag, 0, 4, s));
     magk::incidence_keys(ctx->conn.as<int32_t>(), E, ctx->iperm.as<int32_t>(), N, ctx->sK0.as<uint32_t>(),
                          ctx->sV0.as<uint32_t>(), ctx->deg.as<int32_t>(), errflag, s);
     if (int rc = sort_u32(ctx, ctx->sK0.as<uint32_t>(), ctx->sK1.as<uint32_t>(), ctx->sV0.as<uint32_t>(),
@@ -251,14 +252,16 @@ int ensure_order(mag_ctx *ctx)
                      ctx->iperm.as<int32_t>(), N, B, ctx->hcnt.as<int32_t>(), s);
     if (int rc = scan_i32(ctx, ctx->hcnt.as<int32_t>(), ctx->hoffn.as<int32_t>(), (size_t)N + 1)) return rc;
 
-    int32_t h_err = 0, h_refs = 0;
+    int32_t h_errk[2] = {0, 0}, h_refs = 0;
     int64_t h_total = 0;
-    HIPCHK(hipMemcpyAsync(&h_err, errflag, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_errk, errflag, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&h_total, ctx->tile_off.as<int64_t>() + T, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(&h_refs, ctx->hoffn.as<int32_t>() + N, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (h_err) return fail(ctx, MAG_ERR_BAD_ARGS, "element node index out of range [0, %lld)", (long long)N);
+    if (h_errk[0]) return fail(ctx, MAG_ERR_BAD_ARGS, "element node index out of range [0, %lld)", (long long)N);
     ctx->ell_total = h_total;
+    ctx->nf = 2 * N - h_errk[1];
+    if (ctx->nf == 0) return fail(ctx, MAG_ERR_BC_MISMATCH, "no unknown displacement in the boundary-condition set");
 
     HIPCHK(hipMemsetAsync(ctx->tile_hcnt.p, 0, 4 * ((size_t)T + 1), s));
     int32_t max_halo = 0;
@@ -829,6 +832,112 @@ int cg_phase_fused(mag_ctx *ctx)
     return MAG_OK;
 }
 
+// solver.rs:365-404,427-432,123-137 on the device: K_ff (exact zeros dropped) + b in compact unknown numbering
+int build_reduced(mag_ctx *ctx, bool fill)
+{
+    const int64_t N = ctx->N, n = 2 * N;
+    hipStream_t s = ctx->stream;
+    HIPCHK(ctx->isfree.reserve(4 * ((size_t)n + 1)));
+    HIPCHK(ctx->fidx.reserve(4 * ((size_t)n + 1)));
+    HIPCHK(ctx->rcnt.reserve(4 * ((size_t)n + 1)));
+    HIPCHK(ctx->rowoff.reserve(4 * ((size_t)n + 1)));
+    magk::free_flags(ctx->uknown.as<uint8_t>(), n, ctx->isfree.as<int32_t>(), s);
+    if (int rc = scan_i32(ctx, ctx->isfree.as<int32_t>(), ctx->fidx.as<int32_t>(), (size_t)n + 1)) return rc;
+    magk::reduce_count(ctx->bptr.as<int32_t>(), ctx->bcol.as<int32_t>(), ctx->kval.as<double>(),
+                       ctx->uknown.as<uint8_t>(), N, ctx->rcnt.as<int32_t>(), s);
+    if (int rc = scan_i32(ctx, ctx->rcnt.as<int32_t>(), ctx->rowoff.as<int32_t>(), (size_t)n + 1)) return rc;
+    int32_t h[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(&h[0], ctx->fidx.as<int32_t>() + n, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(&h[1], ctx->rowoff.as<int32_t>() + n, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    ctx->nf = h[0];
+    ctx->nz_ff = h[1];
+    ctx->stats.n_free = ctx->nf;
+    if (ctx->nf == 0) return fail(ctx, MAG_ERR_BC_MISMATCH, "no unknown displacement in the boundary-condition set");
+    if (!fill) return MAG_OK;
+    const int64_t nf = ctx->nf, nz = ctx->nz_ff;
+    HIPCHK(ctx->rp_ff.reserve(4 * ((size_t)nf + 1)));
+    HIPCHK(ctx->col_ff.reserve(4 * (size_t)(nz > 0 ? nz : 1)));
+    HIPCHK(ctx->val_ff.reserve(8 * (size_t)(nz > 0 ? nz : 1)));
+    HIPCHK(ctx->b_ff.reserve(8 * (size_t)nf));
+    magk::reduce_fill(ctx->bptr.as<int32_t>(), ctx->bcol.as<int32_t>(), ctx->kval.as<double>(),
+                      ctx->uknown.as<uint8_t>(), ctx->fidx.as<int32_t>(), ctx->rowoff.as<int32_t>(), N,
+                      ctx->rp_ff.as<int32_t>(), ctx->col_ff.as<int32_t>(), ctx->val_ff.as<double>(), s);
+    magk::rhs_compact(ctx->bptr.as<int32_t>(), ctx->bcol.as<int32_t>(), ctx->kval.as<double>(),
+                      ctx->uknown.as<uint8_t>(), ctx->uin.as<double>(), ctx->fin.as<double>(),
+                      ctx->fidx.as<int32_t>(), N, ctx->b_ff.as<double>(), s);
+    HIPCHK(hipGetLastError());
+    return MAG_OK;
+}
+
+// MAG_OP_CSR: the reference's own iteration (CSR SpMV on K_ff + argmin recurrences), three launches per iteration
+int cg_phase_csr(mag_ctx *ctx)
+{
+    hipStream_t s = ctx->stream;
+    if (ctx->comm.distributed()) return fail(ctx, MAG_ERR_BAD_ARGS, "cg_operator MAG_OP_CSR is single-GPU only");
+    if (int rc = build_reduced(ctx, true)) return rc;
+    const int64_t nf = ctx->nf;
+    const size_t vb = 8 * (size_t)nf;
+    double *x = ctx->x.as<double>(), *r = ctx->r.as<double>(), *q = ctx->q.as<double>();
+    HIPCHK(hipMemsetAsync(x, 0, vb, s));
+    HIPCHK(hipMemsetAsync(ctx->p0.p, 0, vb, s));
+    HIPCHK(hipMemsetAsync(ctx->p1.p, 0, vb, s));
+    magk::csr_init(ctx->b_ff.as<double>(), r, nf, ctx->partRR.as<double>(), s);
+    const int grid = magk::csr_grid(nf);
+    magk::cg_setup(ctx->partRR.as<double>(), grid, ctx->opt.stop_mode, ctx->opt.tol, (long long)ctx->opt.max_iter,
+                   ctx->state.as<CgState>(), s);
+    HIPCHK(hipGetLastError());
+    const int G = ctx->opt.check_every;
+    const long long max_blocks = (long long)(ctx->opt.max_iter / G) + 3;
+    bool done = false;
+    int slot = 0;
+    for (long long blk = 0; blk < max_blocks && !done; ++blk) {
+        for (int i = 0; i < G; ++i) {
+            magk::CsrCgParams P = {};
+            P.n = nf;
+            P.nPart = grid;
+            P.hist_len = ctx->opt.history_len;
+            P.rowptr = ctx->rp_ff.as<int32_t>();
+            P.col = ctx->col_ff.as<int32_t>();
+            P.val = ctx->val_ff.as<double>();
+            P.x = x;
+            P.r = r;
+            P.pprev = (i & 1) ? ctx->p0.as<double>() : ctx->p1.as<double>();
+            P.pnew = (i & 1) ? ctx->p1.as<double>() : ctx->p0.as<double>();
+            P.q = q;
+            P.partRR = ctx->partRR.as<double>();
+            P.partPQ = ctx->partPQ.as<double>();
+            P.st = ctx->state.as<CgState>();
+            P.hist = ctx->hist.as<double>();
+            magk::csr_p_launch(P, s);
+            magk::csr_spmv_launch(P, s);
+            magk::csr_update_launch(nf, r, q, ctx->partPQ.as<double>(), grid, ctx->partRR.as<double>(),
+                                    ctx->state.as<CgState>(), s);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&ctx->h_state[slot], ctx->state.p, sizeof(CgState), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(ctx->evPoll[slot], s));
+        if (blk >= 1) {
+            HIPCHK(hipEventSynchronize(ctx->evPoll[slot ^ 1]));
+            done = ctx->h_state[slot ^ 1].done != 0;
+        }
+        slot ^= 1;
+    }
+    HIPCHK(hipMemcpyAsync(&ctx->h_state[2], ctx->state.p, sizeof(CgState), hipMemcpyDeviceToHost, s));
+    // solver.rs:443-454: the solution goes back into the unknown slots in ascending DOF order
+    magk::expand_free(x, ctx->fidx.as<int32_t>(), ctx->uknown.as<uint8_t>(), ctx->uin.as<double>(), 2 * ctx->N,
+                      ctx->u.as<double>(), s);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    const CgState &st = ctx->h_state[2];
+    ctx->stats.iterations = st.iterations;
+    ctx->stats.final_cost = st.final_cost;
+    ctx->stats.rhs_norm = std::sqrt(st.bb);
+    ctx->stats.converged = st.converged;
+    ctx->stats.breakdown = st.breakdown;
+    return MAG_OK;
+}
+
 double ev_ms(hipEvent_t a, hipEvent_t b)
 {
     float ms = 0.f;
@@ -1019,18 +1128,18 @@ int mag_run(mag_ctx *ctx)
     HIPCHK(hipEventRecord(ctx->ev[5], s));
 
     if (ctx->opt.verbose) printf("info: solving...\n");
-    if (ctx->opt.cg_operator == MAG_OP_CSR)
-        return fail(ctx, MAG_ERR_BAD_ARGS, "cg_operator MAG_OP_CSR is not available in this build");
-    if (int rc = ctx->fused ? cg_phase_fused(ctx) : cg_phase(ctx)) return rc;
+    HIPCHK(ctx->u.reserve(16 * (size_t)N));
+    HIPCHK(ctx->f.reserve(16 * (size_t)N));
+    HIPCHK(ctx->stress.reserve(8 * (size_t)E));
+    const bool csr_op = ctx->opt.cg_operator == MAG_OP_CSR;
+    if (int rc = csr_op ? cg_phase_csr(ctx) : (ctx->fused ? cg_phase_fused(ctx) : cg_phase(ctx))) return rc;
     HIPCHK(hipEventRecord(ctx->ev[6], s));
     if (ctx->opt.verbose)
         printf("info: finished conjugate gradient approximation in %lld iterations\n", (long long)st.iterations);
 
-    HIPCHK(ctx->u.reserve(16 * (size_t)N));
-    HIPCHK(ctx->f.reserve(16 * (size_t)N));
-    HIPCHK(ctx->stress.reserve(8 * (size_t)E));
-    magk::scatter_back(ctx->x.as<double>(), ctx->perm.as<uint32_t>(), ctx->uknown.as<uint8_t>(), ctx->uin.as<double>(),
-                       N, ctx->u.as<double>(), s);
+    if (!csr_op)
+        magk::scatter_back(ctx->x.as<double>(), ctx->perm.as<uint32_t>(), ctx->uknown.as<uint8_t>(),
+                           ctx->uin.as<double>(), N, ctx->u.as<double>(), s);
     if (csr) {
         magk::reactions_from_csr(ctx->bptr.as<int32_t>(), ctx->bcol.as<int32_t>(), ctx->kval.as<double>(),
                                  ctx->uknown.as<uint8_t>(), ctx->u.as<double>(), ctx->fin.as<double>(), N,
@@ -1063,9 +1172,7 @@ int mag_run(mag_ctx *ctx)
     st.halo_nodes = ctx->halo_total;
     st.max_tile_halo = ctx->max_halo;
     st.lds_operator = ctx->use_lds ? 1 : 0;
-    // n_free is only needed for reporting; count on the host side of the mask would cost a pass, so
-    // take it from the mask on the device lazily in mag_reduce_system; here report -1 if unknown.
-    st.n_free = -1;
+    st.n_free = ctx->nf;
     ctx->have_run = true;
     if (st.breakdown) return fail(ctx, MAG_ERR_NOT_CONVERGED, "Conjugate Gradient error: non-finite residual after %lld iterations", (long long)st.iterations);
     if (!st.converged)
@@ -1158,46 +1265,20 @@ int mag_reduce_system(mag_ctx *ctx, int64_t *n_free, int64_t *nnz_ff, int32_t *r
     if (int rc = enter(ctx)) return rc;
     if (!ctx->have_problem) return fail(ctx, MAG_ERR_STATE, "no problem uploaded");
     if (int rc = ensure_csr(ctx)) return rc;
-    const int64_t N = ctx->N, n = 2 * N;
-    hipStream_t s = ctx->stream;
-    HIPCHK(ctx->isfree.reserve(4 * ((size_t)n + 1)));
-    HIPCHK(ctx->fidx.reserve(4 * ((size_t)n + 1)));
-    HIPCHK(ctx->rcnt.reserve(4 * ((size_t)n + 1)));
-    HIPCHK(ctx->rowoff.reserve(4 * ((size_t)n + 1)));
-    magk::free_flags(ctx->uknown.as<uint8_t>(), n, ctx->isfree.as<int32_t>(), s);
-    if (int rc = scan_i32(ctx, ctx->isfree.as<int32_t>(), ctx->fidx.as<int32_t>(), (size_t)n + 1)) return rc;
-    magk::reduce_count(ctx->bptr.as<int32_t>(), ctx->bcol.as<int32_t>(), ctx->kval.as<double>(),
-                       ctx->uknown.as<uint8_t>(), N, ctx->rcnt.as<int32_t>(), s);
-    if (int rc = scan_i32(ctx, ctx->rcnt.as<int32_t>(), ctx->rowoff.as<int32_t>(), (size_t)n + 1)) return rc;
-    int32_t h[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(&h[0], ctx->fidx.as<int32_t>() + n, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(&h[1], ctx->rowoff.as<int32_t>() + n, 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    const int64_t nf = h[0], nz = h[1];
+    const bool fill = rowptr || col || val || b;
+    if (int rc = build_reduced(ctx, fill)) {
+        if (n_free) *n_free = ctx->nf;
+        if (nnz_ff) *nnz_ff = ctx->nz_ff;
+        return rc;
+    }
+    const int64_t nf = ctx->nf, nz = ctx->nz_ff;
     if (n_free) *n_free = nf;
     if (nnz_ff) *nnz_ff = nz;
-    ctx->stats.n_free = nf;
-    if (nf == 0) return fail(ctx, MAG_ERR_BC_MISMATCH, "no unknown displacement in the boundary-condition set");
-    if (rowptr || col || val) {
-        HIPCHK(ctx->rp_ff.reserve(4 * ((size_t)nf + 1)));
-        HIPCHK(ctx->col_ff.reserve(4 * (size_t)(nz > 0 ? nz : 1)));
-        HIPCHK(ctx->val_ff.reserve(8 * (size_t)(nz > 0 ? nz : 1)));
-        magk::reduce_fill(ctx->bptr.as<int32_t>(), ctx->bcol.as<int32_t>(), ctx->kval.as<double>(),
-                          ctx->uknown.as<uint8_t>(), ctx->fidx.as<int32_t>(), ctx->rowoff.as<int32_t>(), N,
-                          ctx->rp_ff.as<int32_t>(), ctx->col_ff.as<int32_t>(), ctx->val_ff.as<double>(), s);
-        HIPCHK(hipGetLastError());
-        if (rowptr) HIPCHK(hipMemcpyAsync(rowptr, ctx->rp_ff.p, 4 * ((size_t)nf + 1), hipMemcpyDeviceToHost, s));
-        if (col && nz) HIPCHK(hipMemcpyAsync(col, ctx->col_ff.p, 4 * (size_t)nz, hipMemcpyDeviceToHost, s));
-        if (val && nz) HIPCHK(hipMemcpyAsync(val, ctx->val_ff.p, 8 * (size_t)nz, hipMemcpyDeviceToHost, s));
-    }
-    if (b) {
-        HIPCHK(ctx->b_ff.reserve(8 * (size_t)nf));
-        magk::rhs_compact(ctx->bptr.as<int32_t>(), ctx->bcol.as<int32_t>(), ctx->kval.as<double>(),
-                          ctx->uknown.as<uint8_t>(), ctx->uin.as<double>(), ctx->fin.as<double>(),
-                          ctx->fidx.as<int32_t>(), N, ctx->b_ff.as<double>(), s);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(b, ctx->b_ff.p, 8 * (size_t)nf, hipMemcpyDeviceToHost, s));
-    }
+    hipStream_t s = ctx->stream;
+    if (rowptr) HIPCHK(hipMemcpyAsync(rowptr, ctx->rp_ff.p, 4 * ((size_t)nf + 1), hipMemcpyDeviceToHost, s));
+    if (col && nz) HIPCHK(hipMemcpyAsync(col, ctx->col_ff.p, 4 * (size_t)nz, hipMemcpyDeviceToHost, s));
+    if (val && nz) HIPCHK(hipMemcpyAsync(val, ctx->val_ff.p, 8 * (size_t)nz, hipMemcpyDeviceToHost, s));
+    if (b) HIPCHK(hipMemcpyAsync(b, ctx->b_ff.p, 8 * (size_t)nf, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return MAG_OK;
 }

@@ -720,6 +720,138 @@ void cg_setup(const double *partRR, int32_t nPart, int stop_mode, double tol, lo
     k_cg_setup<<<1, 256, 0, s>>>(partRR, nPart, stop_mode, tol, max_iter, st);
 }
 
+// ============================================ reference-faithful CSR CG ===
+// MAG_OP_CSR: what the reference runs per iteration (solver.rs:23-37 + argmin's next_iter), on K_ff in CSR with
+// the unknowns in ascending DOF order (solver.rs:443-450): three launches per iteration, same device-side state
+// machine as the two-launch matrix-free variant.  Kept for A/B against the matrix-free operator, not for speed.
+int csr_grid(int64_t n)
+{
+    int64_t g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > kMaxGrid ? kMaxGrid : g));
+}
+
+__global__ void __launch_bounds__(256) k_csr_p(const CsrCgParams P)
+{
+    __shared__ double s_red[4];
+    CgState *st = P.st;
+    const long long k = st->iterA;
+    const int was_done = st->done;
+    const double alpha = st->alpha_last;
+    const double rrh0 = st->rr_hist[0], rrh1 = st->rr_hist[1];
+    const double rr = sum_partials<256>(P.partRR, P.nPart, s_red);
+    if (was_done) return;
+    const double cost = st->stop_mode == 1 ? fabs(rr) : sqrt(rr);
+    const bool finished = (k >= 1) && (cost <= st->target);
+    const bool broke = !(fabs(rr) <= 1.79769313486231570e308);
+    const bool maxed = k >= st->max_iter;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (k >= 1 && k - 1 < P.hist_len) P.hist[k - 1] = cost;
+        if (finished || broke || maxed) {
+            st->iterations = k;
+            st->final_cost = cost;
+            st->converged = finished ? 1 : 0;
+            st->breakdown = broke ? 1 : 0;
+            st->done = 1;
+        } else {
+            st->rr_hist[k & 1] = rr;
+            st->iterB = k;
+        }
+    }
+    const bool stop = finished || broke || maxed;
+    const double rr_prev = (k == 0) ? rr : ((k & 1) ? rrh0 : rrh1);
+    const double beta = rr / rr_prev;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P.n; i += (int64_t)gridDim.x * 256) {
+        const double pp = P.pprev[i];
+        if (!broke) P.x[i] += alpha * pp; // x += alpha_{k-1} p_{k-1}
+        if (!stop) P.pnew[i] = -P.r[i] + beta * pp;
+    }
+}
+
+void csr_p_launch(const CsrCgParams &P, hipStream_t s) { k_csr_p<<<csr_grid(P.n), 256, 0, s>>>(P); }
+
+__global__ void __launch_bounds__(256) k_csr_spmv(const CsrCgParams P)
+{
+    __shared__ double s_red[4];
+    const int done = P.st->done;
+    double acc = 0.0;
+    if (!done) {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P.n; i += (int64_t)gridDim.x * 256) {
+            double sum = 0.0;
+            for (int32_t e = P.rowptr[i]; e < P.rowptr[i + 1]; ++e) sum += P.val[e] * P.pnew[P.col[e]];
+            P.q[i] = sum;
+            acc += P.pnew[i] * sum;
+        }
+    }
+    const double tot = block_sum<256>(acc, s_red);
+    if (threadIdx.x == 0) P.partPQ[blockIdx.x] = tot;
+}
+
+void csr_spmv_launch(const CsrCgParams &P, hipStream_t s) { k_csr_spmv<<<csr_grid(P.n), 256, 0, s>>>(P); }
+
+__global__ void __launch_bounds__(256) k_csr_update(int64_t n, double *r, const double *q, const double *partPQ,
+                                                    int nPart, double *partRR, CgState *st)
+{
+    __shared__ double s_red[4];
+    const int done = st->done;
+    const long long k = st->iterB;
+    const double rrh0 = st->rr_hist[0], rrh1 = st->rr_hist[1];
+    const double pq = sum_partials<256>(partPQ, nPart, s_red);
+    if (done) return;
+    const double alpha = ((k & 1) ? rrh1 : rrh0) / pq;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = r[i] + alpha * q[i];
+        r[i] = v;
+        acc += v * v;
+    }
+    const double tot = block_sum<256>(acc, s_red);
+    if (threadIdx.x == 0) {
+        partRR[blockIdx.x] = tot;
+        if (blockIdx.x == 0) {
+            st->iterA = k + 1;
+            st->alpha_last = alpha;
+        }
+    }
+}
+
+void csr_update_launch(int64_t n, double *r, const double *q, const double *partPQ, int32_t nPart, double *partRR,
+                       CgState *st, hipStream_t s)
+{
+    k_csr_update<<<csr_grid(n), 256, 0, s>>>(n, r, q, partPQ, nPart, partRR, st);
+}
+
+__global__ void __launch_bounds__(256) k_csr_init(const double *b, double *r, int64_t n, double *partRR)
+{
+    __shared__ double s_red[4];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = -b[i];
+        r[i] = v;
+        acc += v * v;
+    }
+    const double tot = block_sum<256>(acc, s_red);
+    if (threadIdx.x == 0) partRR[blockIdx.x] = tot;
+}
+
+void csr_init(const double *b, double *r, int64_t n, double *partRR, hipStream_t s)
+{
+    k_csr_init<<<csr_grid(n), 256, 0, s>>>(b, r, n, partRR);
+}
+
+// solver.rs:443-454: unknown slots filled in ascending DOF order from the CG solution
+__global__ void __launch_bounds__(256) k_expand_free(const double *xf, const int32_t *fidx, const uint8_t *u_known,
+                                                     const double *u_in, int64_t n2, double *u)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n2) u[i] = u_known[i] ? u_in[i] : xf[fidx[i]];
+}
+
+void expand_free(const double *xf, const int32_t *fidx, const uint8_t *u_known, const double *u_in, int64_t n2,
+                 double *u, hipStream_t s)
+{
+    k_expand_free<<<(int)((n2 + 255) / 256), 256, 0, s>>>(xf, fidx, u_known, u_in, n2, u);
+}
+
 // ======================================================= fused CG iteration ===
 // ONE launch per CG iteration.  Launch j produces iterate j from iterate j-1 and the four dot products of
 // iterate j-1 (r.r, p.q, r.q, q.q, reduced from the previous launch's per-workgroup partials):

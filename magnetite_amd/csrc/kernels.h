@@ -20,7 +20,7 @@ void bbox(const double *xy, int64_t N, double *scratch, double *bbox4, hipStream
 void hilbert_keys(const double *xy, int64_t N, const double *bbox4, uint32_t *keys, uint32_t *ids, hipStream_t s);
 // perm = new->old (sorted ids).  Writes iperm (old->new), xyP[new] and maskP[new] = known_x | known_y<<1
 void apply_order(const uint32_t *perm, const double *xy, const uint8_t *u_known, int64_t N, int32_t *iperm,
-                 double *xyP, uint8_t *maskP, hipStream_t s);
+                 double *xyP, uint8_t *maskP, int32_t *known_count, hipStream_t s);
 // per element corner k=3e+c: keys[k] = iperm[conn[k]], vals[k] = k, deg[key]++ ; out-of-range conn sets *err
 void incidence_keys(const int32_t *conn, int64_t E, const int32_t *iperm, int64_t N, uint32_t *keys,
                     uint32_t *vals, int32_t *deg, int32_t *err, hipStream_t s);
@@ -164,6 +164,36 @@ struct UpdParams {
     CgState *st;
     int32_t wt;
 };
+
+// ---- reference-faithful CG on K_ff in CSR (MAG_OP_CSR): compact unknown numbering, solver.rs:31-36 ----
+struct CsrCgParams {
+    int64_t n;      // unknowns
+    int32_t nPart;  // partials written by the previous launch
+    int32_t hist_len;
+    const int32_t *rowptr;
+    const int32_t *col;
+    const double *val;
+    double *x;
+    const double *r;
+    const double *pprev;
+    double *pnew;
+    double *q;
+    const double *partRR;
+    double *partPQ;
+    CgState *st;
+    double *hist;
+};
+// p = -r + beta p_prev, x += alpha_prev p_prev (state machine of the two-launch variant)
+void csr_p_launch(const CsrCgParams &P, hipStream_t s);
+// q = K_ff p, row sums in ascending column order; p.q partials
+void csr_spmv_launch(const CsrCgParams &P, hipStream_t s);
+// r += alpha q; r.r partials (plain double arrays)
+void csr_update_launch(int64_t n, double *r, const double *q, const double *partPQ, int32_t nPart, double *partRR,
+                       CgState *st, hipStream_t s);
+void csr_init(const double *b, double *r, int64_t n, double *partRR, hipStream_t s);
+int csr_grid(int64_t n);
+void expand_free(const double *xf, const int32_t *fidx, const uint8_t *u_known, const double *u_in, int64_t n2,
+                 double *u, hipStream_t s);
 
 // ---- fused single-launch CG iteration (cg_variant 1) ----
 // One record per node keeps what a neighbouring tile must read of it in one place: r, q = A p, p.

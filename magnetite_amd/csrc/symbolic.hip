@@ -125,21 +125,24 @@ void hilbert_keys(const double *xy, int64_t N, const double *bbox4, uint32_t *ke
 }
 
 __global__ void __launch_bounds__(256) k_apply_order(const uint32_t *perm, const double2 *xy, const uint8_t *u_known,
-                                                     int64_t N, int32_t *iperm, double2 *xyP, uint8_t *maskP)
+                                                     int64_t N, int32_t *iperm, double2 *xyP, uint8_t *maskP,
+                                                     int32_t *known_count)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const uint32_t o = perm[i];
     iperm[o] = (int32_t)i;
     xyP[i] = xy[o];
-    maskP[i] = (uint8_t)((u_known[2 * (int64_t)o] ? 1 : 0) | (u_known[2 * (int64_t)o + 1] ? 2 : 0));
+    const int kx = u_known[2 * (int64_t)o] ? 1 : 0, ky = u_known[2 * (int64_t)o + 1] ? 1 : 0;
+    maskP[i] = (uint8_t)(kx | (ky << 1));
+    if (kx + ky) atomicAdd(known_count, kx + ky); // prescribed displacements (solver.rs:370)
 }
 
 void apply_order(const uint32_t *perm, const double *xy, const uint8_t *u_known, int64_t N, int32_t *iperm,
-                 double *xyP, uint8_t *maskP, hipStream_t s)
+                 double *xyP, uint8_t *maskP, int32_t *known_count, hipStream_t s)
 {
     k_apply_order<<<blocks_for(N, 256), 256, 0, s>>>(perm, (const double2 *)xy, u_known, N, iperm, (double2 *)xyP,
-                                                     maskP);
+                                                     maskP, known_count);
 }
 
 // ----------------------------------------------------------- incidence ---

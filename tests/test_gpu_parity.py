@@ -9,7 +9,8 @@ import pytest
 
 import oracle
 from magnetite_amd import Context, MagnetiteError, meshgen
-from magnetite_amd._lib import MAG_ERR_BAD_ARGS, MAG_STOP_REL, MAG_STOP_RNORM_SQ
+from magnetite_amd._lib import (MAG_ERR_BAD_ARGS, MAG_ERR_BC_MISMATCH, MAG_OP_CSR, MAG_STOP_REL,
+                                MAG_STOP_RNORM_SQ)
 
 pytestmark = pytest.mark.gpu
 
@@ -137,6 +138,47 @@ def test_stop_modes_and_eager(built):
         assert out["converged"] == 1, kw
         assert rel(out["u"], ref["u"]) <= (1e-6 if kw.get("stop_mode") == MAG_STOP_REL else TOL_U), kw
         assert abs(out["iterations"] - ref["iterations"]) <= max(3, ref["iterations"] // 50), kw
+
+
+@pytest.mark.parametrize("name", ["plate_shuffled", "hole_perturbed", "clockwise"])
+def test_csr_operator_mode_is_the_reference_iteration(built, name):
+    """MAG_OP_CSR: CG on K_ff in CSR, compact ascending-DOF numbering, row sums in ascending column order --
+    solver.rs:23-37 + argmin, i.e. exactly what the oracle's orc_cg does; only the dot products are summed
+    in a different order."""
+    p = PROBLEMS[name]
+    ref = oracle_run(p, hist_len=32)
+    with Context(device=0, cg_operator=MAG_OP_CSR, history_len=32) as c:
+        out = c.solve(p)
+        hist = c.history(min(32, out["iterations"]))
+    assert out["converged"] == 1 and out["n_free"] == ref["n_free"]
+    assert rel(out["u"], ref["u"]) <= TOL_U
+    n = min(len(hist), len(ref["history"]))
+    assert np.allclose(hist[:n], ref["history"][:n], rtol=1e-10)
+    assert abs(out["iterations"] - ref["iterations"]) <= max(3, ref["iterations"] // 50)
+    with Context(device=0) as c:
+        mf = c.solve(p)
+    assert rel(mf["u"], out["u"]) <= 1e-9 and mf["n_free"] == ref["n_free"]
+
+
+def test_unreferenced_nodes_and_all_prescribed(built):
+    """Nodes no element uses have empty rows of K (u stays 0 there); a BC set with no unknown is an error."""
+    m = meshgen.plate(6)
+    xy = np.concatenate([m.xy, [[5.0, 5.0], [6.0, 5.0]]])
+    p = meshgen.config_fixed_left_pull_right(meshgen.Mesh(m.xy, m.conn))
+    uk = np.concatenate([p.u_known, [0, 0, 0, 0]]).astype(np.uint8)
+    ui = np.concatenate([p.u_in, np.zeros(4)])
+    fi = np.concatenate([p.f_in, np.zeros(4)])
+    with Context(device=0) as c:
+        c.upload(xy.reshape(-1), m.conn.reshape(-1), uk, ui, fi, p.youngs_modulus, p.poisson_ratio, p.part_thickness)
+        c.run()
+        u, f, s = c.download()
+    ref = oracle_run(p)
+    assert rel(u[:-4], ref["u"]) <= TOL_U and not u[-4:].any()
+    with Context(device=0) as c:
+        c.upload(m.xy.reshape(-1), m.conn.reshape(-1), np.ones_like(p.u_known), p.u_in, p.f_in, 1.0, 0.3, 1.0)
+        with pytest.raises(MagnetiteError) as ei:
+            c.run()
+        assert ei.value.code == MAG_ERR_BC_MISMATCH
 
 
 def test_run_to_run_bitwise_reproducible(built):
