@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-iters", type=int, default=150)
     ap.add_argument("--op-reps", type=int, default=400)
+    ap.add_argument("--rehearse-dist", action="store_true",
+                    help="world size 1 only: still create the nccl process group and the RCCL communicator and run "
+                         "the distributed CG protocol (pack / all-reduce / unpack every iteration)")
     args = ap.parse_args()
 
     import torch  # first: libmagnetite_hip.so then shares torch's HIP runtime and RCCL (same SONAMEs)
@@ -100,7 +103,14 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the solver has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.rehearse_dist
+    if args.rehearse_dist:
+        os.environ["MAG_TUNE_FORCE_DIST"] = "1"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     stop_mode = {"rel": _lib.MAG_STOP_REL, "rnorm": _lib.MAG_STOP_RNORM, "rnorm_sq": _lib.MAG_STOP_RNORM_SQ}[args.stop]
@@ -109,12 +119,12 @@ def main():
 
     ctx = Context(device=local_rank, stop_mode=stop_mode, tol=args.tol, tile_nodes=args.tile,
                   check_every=args.check_every, use_graph=0 if args.no_graph else 1, cg_variant=args.cg_variant)
-    if world > 1:
+    if use_dist:
         ctx.init_rccl_from_torch(dist, rank, world)
     ctx.upload_problem(prob)  # inputs resident in HBM before the timed region
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -126,7 +136,7 @@ def main():
         ctx.run()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -192,7 +202,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
