@@ -173,6 +173,10 @@ int mag_get_history(mag_ctx *ctx, double *history, int64_t n);
 /* ---- pieces of the path, exposed for parity tests -------------------- */
 /* solver.rs:187-193 compute_element_area (pub; the mesher imports it, mesher.rs:9,523). Host-side. */
 double mag_compute_element_area(const double *xy, const int32_t *tri);
+/* solver.rs:204-230 compute_strain_displacement_matrix (pub): B[18], 3x6 row major, entries divided by 2*area. */
+void mag_compute_strain_displacement_matrix(const double *xy, const int32_t *tri, double element_area, double *B);
+/* solver.rs:240-250 compute_stress_strain_matrix (pub): D[9], 3x3 row major, plane stress. */
+void mag_compute_stress_strain_matrix(double poisson_ratio, double youngs_modulus, double *D);
 /* solver.rs:263-278 for every element of the uploaded problem: ke_out[36E] host, row-major 6x6. */
 int mag_element_stiffness(mag_ctx *ctx, double *ke_out);
 /* solver.rs:290-331: K (2N x 2N) in CSR, ascending columns, structural pattern.

@@ -23,6 +23,7 @@ MAG_UNIQUE_ID_BYTES = 128
 SYMBOLS = [
     "mag_version", "mag_default_options", "mag_create", "mag_destroy", "mag_last_error", "mag_solve",
     "mag_upload", "mag_run", "mag_download", "mag_get_stats", "mag_get_history", "mag_compute_element_area",
+    "mag_compute_strain_displacement_matrix", "mag_compute_stress_strain_matrix",
     "mag_element_stiffness", "mag_assemble_csr", "mag_reduce_system", "mag_apply_operator", "mag_time_operator", "mag_time_spmv",
     "mag_comm_get_unique_id", "mag_comm_init_rccl", "mag_comm_init_callback",
 ]
@@ -98,6 +99,10 @@ def lib():
     L.mag_get_history.argtypes = [vp, dp, C.c_int64]
     L.mag_compute_element_area.argtypes = [dp, ip]
     L.mag_compute_element_area.restype = C.c_double
+    L.mag_compute_strain_displacement_matrix.argtypes = [dp, ip, C.c_double, dp]
+    L.mag_compute_strain_displacement_matrix.restype = None
+    L.mag_compute_stress_strain_matrix.argtypes = [C.c_double, C.c_double, dp]
+    L.mag_compute_stress_strain_matrix.restype = None
     L.mag_element_stiffness.argtypes = [vp, dp]
     L.mag_assemble_csr.argtypes = [vp, C.POINTER(C.c_int64), ip, ip, dp]
     L.mag_reduce_system.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), ip, ip, dp, dp]

@@ -1050,6 +1050,28 @@ double mag_compute_element_area(const double *xy, const int32_t *tri)
     return 0.5 * (x0 * (y1 - y2) + x1 * (y2 - y0) + x2 * (y0 - y1));
 }
 
+void mag_compute_strain_displacement_matrix(const double *xy, const int32_t *tri, double element_area, double *B)
+{
+    // solver.rs:204-230 (host-side twin of exact.hip:strain_displacement)
+    const double x0 = xy[2 * tri[0]], y0 = xy[2 * tri[0] + 1];
+    const double x1 = xy[2 * tri[1]], y1 = xy[2 * tri[1] + 1];
+    const double x2 = xy[2 * tri[2]], y2 = xy[2 * tri[2] + 1];
+    const double b1 = y1 - y2, b2 = y2 - y0, b3 = y0 - y1;
+    const double g1 = x2 - x1, g2 = x0 - x2, g3 = x1 - x0;
+    const double m[18] = {b1, 0., b2, 0., b3, 0., 0., g1, 0., g2, 0., g3, g1, b1, g2, b2, g3, b3};
+    const double d = 2.0 * element_area;
+    for (int i = 0; i < 18; ++i) B[i] = m[i] / d;
+}
+
+void mag_compute_stress_strain_matrix(double poisson_ratio, double youngs_modulus, double *D)
+{
+    // solver.rs:240-250
+    const double nu = poisson_ratio;
+    const double m[9] = {1.0, nu, 0.0, nu, 1.0, 0.0, 0.0, 0.0, (1.0 - nu) / 2.0};
+    const double s = youngs_modulus / (1.0 - nu * nu);
+    for (int i = 0; i < 9; ++i) D[i] = m[i] * s;
+}
+
 int mag_upload(mag_ctx *ctx, const mag_problem *p)
 {
     if (int rc = enter(ctx)) return rc;

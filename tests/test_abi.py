@@ -78,6 +78,25 @@ def test_compute_element_area_is_the_reference_formula(built):
         assert a == oracle.element_area(xy, tri)
 
 
+def test_pub_matrix_functions_match_the_oracle_bitwise(built):
+    """solver.rs:204-230 and :240-250 are pub in the reference; the library keeps host-side twins."""
+    L = _lib.lib()
+    rng = np.random.default_rng(11)
+    for _ in range(50):
+        xy = rng.uniform(-10, 10, size=8)
+        tri = rng.permutation(4)[:3].astype(np.int32)
+        area = oracle.element_area(xy, tri)
+        B = np.empty(18)
+        L.mag_compute_strain_displacement_matrix(xy.ctypes.data_as(C.POINTER(C.c_double)),
+                                                 tri.ctypes.data_as(C.POINTER(C.c_int32)), area,
+                                                 B.ctypes.data_as(C.POINTER(C.c_double)))
+        assert np.array_equal(B.reshape(3, 6), oracle.strain_displacement(xy, tri, area))
+        nu, E = rng.uniform(0.0, 0.49), rng.uniform(1.0, 1e11)
+        D = np.empty(9)
+        L.mag_compute_stress_strain_matrix(nu, E, D.ctypes.data_as(C.POINTER(C.c_double)))
+        assert np.array_equal(D.reshape(3, 3), oracle.stress_strain(nu, E))
+
+
 def test_no_cpu_fallback(built):
     """On a box without a HIP device the product path must fail loudly, never compute on the CPU."""
     probe = subprocess.run([sys.executable, "-c", "import torch,sys; sys.exit(0 if torch.cuda.is_available() else 3)"],

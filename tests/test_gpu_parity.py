@@ -181,6 +181,27 @@ def test_unreferenced_nodes_and_all_prescribed(built):
         assert ei.value.code == MAG_ERR_BC_MISMATCH
 
 
+def test_config5_size_multihole_16m(built):
+    """BASELINE config 5 geometry (16M-triangle multi-hole plate) on one GPU: one solve, checked through the
+    operator itself (K_ff u_f = b to round-off of the right-hand-side scale) and through symmetry of K."""
+    p = meshgen.baseline_problem("multihole16m")
+    n = 2 * p.mesh.num_nodes
+    assert p.mesh.num_elements > 15_500_000
+    rng = np.random.default_rng(5)
+    with Context(device=0, stop_mode=MAG_STOP_REL, tol=1e-9) as c:
+        out = c.solve(p)
+        assert out["converged"] == 1 and out["lds_operator"] == 1
+        x, y = rng.standard_normal(n), rng.standard_normal(n)
+        Ky = c.apply_operator(y)
+        assert abs(x @ Ky - y @ c.apply_operator(x)) <= 1e-11 * np.linalg.norm(x) * np.linalg.norm(Ky)
+        free = p.u_known == 0
+        res = (c.apply_operator(out["u"]) - p.f_in)[free]
+        fs = np.abs(c.apply_operator(np.where(free, 0.0, out["u"]))).max()
+        assert np.linalg.norm(res) <= 1e-7 * fs * np.sqrt(free.sum())
+    k = p.u_known == 1
+    assert np.array_equal(out["u"][k], p.u_in[k])
+
+
 def test_run_to_run_bitwise_reproducible(built):
     p = PROBLEMS["multihole"]
     with Context(device=0) as c:
@@ -298,7 +319,7 @@ def test_high_valence_fan_mesh(built):
         assert rel(out["u"], ref["u"]) <= TOL_U
 
 
-@pytest.mark.parametrize("which,scale", [("hole1m", 1.0), ("plate100k", 1.0)])
+@pytest.mark.parametrize("which,scale", [("hole1m", 1.0), ("plate100k", 1.0), ("plate4m", 1.0)])
 def test_full_size_properties(built, which, scale):
     """BASELINE-size meshes, where the oracle does not finish in seconds: size-independent properties.
     (1) K is symmetric: x.(Ky) == y.(Kx); (2) rigid translations are in the null space of the unmasked K;
