@@ -1373,16 +1373,9 @@ int mag_time_operator(mag_ctx *ctx, int32_t reps, double *ms_per_launch)
     magk::UpdParams U;
     iteration_params(ctx, 0, P, U);
     P.hist_len = 0;
-    const char *what = getenv("MAG_TUNE_TIMEWHAT");
-    const int tw = what ? atoi(what) : 0;
     for (int i = 0; i < 3; ++i) magk::op_launch(P, ctx->B, true, s);
     HIPCHK(hipEventRecord(ctx->ev[8], s));
-    for (int i = 0; i < reps; ++i) {
-        if (tw == 1)
-            magk::upd_launch(U, ctx->B, s);
-        else
-            magk::op_launch(P, ctx->B, true, s);
-    }
+    for (int i = 0; i < reps; ++i) magk::op_launch(P, ctx->B, true, s);
     HIPCHK(hipEventRecord(ctx->ev[9], s));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));

@@ -87,3 +87,68 @@ def test_input_json_errors(tmp_path, mutate, msg):
         parse_boundary_rules(doc)
     with pytest.raises(MagnetiteError, match="Unable to open input file"):
         load_input_file(str(tmp_path / "missing.json"))
+
+
+MSH_SAMPLE = """$MeshFormat
+4.1 0 8
+$EndMeshFormat
+$Entities
+4 4 1 0
+1 0 0 0 0
+2 2 0 0 0
+3 2 2 0 0
+4 0 2 0 0
+1 0 0 0 2 0 0 0 2 1 -2
+$EndEntities
+$Nodes
+3 5 1 5
+0 1 0 1
+1
+0 0 0
+1 1 0 2
+2
+3
+2 0 0
+2 2 0
+2 1 0 2
+5
+4
+1 1 0
+0 2 0
+$EndNodes
+$Elements
+2 6 1 6
+1 1 1 2
+1 1 2
+2 2 3
+2 1 2 4
+3 1 2 5
+4 2 3 5
+5 3 4 5
+6 4 1 5
+$EndElements
+"""
+
+
+def test_msh4_reader_follows_the_reference_parser(tmp_path):
+    from magnetite_amd.msh import parse_mesh, write_msh
+    path = tmp_path / "geom.msh"
+    path.write_text(MSH_SAMPLE)
+    raw = parse_mesh(str(path), apply_check_ccw=False)
+    # node tags place the nodes (the second surface block lists tag 5 before tag 4), z dropped
+    assert raw.xy.tolist() == [[0, 0], [2, 0], [2, 2], [0, 2], [1, 1]]
+    # the two line elements (entityDim 1) are skipped, triangles are 0-based
+    assert raw.conn.tolist() == [[0, 1, 4], [1, 2, 4], [2, 3, 4], [3, 0, 4]]
+    a = raw.xy[raw.conn]
+    area = 0.5 * ((a[:, 1, 0] - a[:, 0, 0]) * (a[:, 2, 1] - a[:, 0, 1]) - (a[:, 2, 0] - a[:, 0, 0]) * (a[:, 1, 1] - a[:, 0, 1]))
+    assert np.allclose(area, 1.0)
+    # mesher.rs:522-526: area < 1.0 => reversed; area == 1.0 exactly stays
+    assert parse_mesh(str(path)).conn.tolist() == raw.conn.tolist()
+    fine = meshgen.shuffle(meshgen.plate_with_holes(12), 3)
+    out = tmp_path / "fine.msh"
+    write_msh(fine, str(out))
+    back = parse_mesh(str(out), apply_check_ccw=False)
+    assert np.array_equal(back.xy, fine.xy) and np.array_equal(back.conn, fine.conn)
+    assert np.array_equal(parse_mesh(str(out)).conn, fine.conn[:, ::-1])  # every fine element gets reversed
+    with pytest.raises(MagnetiteError, match="Mesher error: Unable to open"):
+        parse_mesh(str(tmp_path / "nope.msh"))
