@@ -93,7 +93,10 @@ typedef struct mag_options {
                              (r.r + 2 alpha r.q + alpha^2 q.q) so that one grid-wide reduction per iteration
                              suffices; alpha, the stop test and the reported cost use the true r.r.
                              0: two launches per iteration, argmin's recurrences to the letter              */
-    int32_t reserved[3];
+    int32_t precision;    /* 0 (default): fp64 everywhere, as the reference.  1: the CG state, the operator and
+                             (tile-relative) coordinates in fp32, dot products accumulated in fp64 -- the fp32
+                             leg of BASELINE config 5's tolerance sweep; cannot meet the 1e-8 parity bar         */
+    int32_t reserved[2];
 } mag_options;
 
 /* Borrowed view of the caller's flattened Vec<Node>/Vec<Element>/ModelMetadata

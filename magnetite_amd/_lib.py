@@ -33,7 +33,8 @@ class Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("stop_mode", C.c_int32), ("tol", C.c_double), ("max_iter", C.c_int64),
                 ("cg_operator", C.c_int32), ("assemble_csr", C.c_int32), ("check_every", C.c_int32),
                 ("use_graph", C.c_int32), ("tile_nodes", C.c_int32), ("history_len", C.c_int32),
-                ("verbose", C.c_int32), ("op_variant", C.c_int32), ("cg_variant", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("verbose", C.c_int32), ("op_variant", C.c_int32), ("cg_variant", C.c_int32), ("precision", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
 
 
 class Problem(C.Structure):

@@ -104,6 +104,7 @@ struct mag_ctx {
     magk::FusedState *h_fstate = nullptr; // pinned, 3 slots
     bool fused = false;
     int32_t fgrid = 1; // workgroups of the fused kernel for this problem
+    DevBuf xy32, hxy32, rqp32a, rqp32b, x32; // fp32 leg (mag_options.precision = 1)
     hipGraphExec_t graph = nullptr;
     struct GraphKey {
         void *ptrs[20];
@@ -938,6 +939,85 @@ int cg_phase_csr(mag_ctx *ctx)
     return MAG_OK;
 }
 
+// fp32 leg of BASELINE config 5: same fused iteration, CG state and operator arithmetic in fp32 (cg.hip, k_cg_fused32)
+int cg_phase_fused32(mag_ctx *ctx)
+{
+    using magk::FusedState;
+    hipStream_t s = ctx->stream;
+    if (!ctx->use_lds || ctx->dist || ctx->B == 1024)
+        return fail(ctx, MAG_ERR_BAD_ARGS, "precision fp32 needs the LDS-halo operator, tile_nodes 256|512 and one GPU");
+    const int64_t N = ctx->N;
+    const int32_t stride = magk::kMaxGrid;
+    HIPCHK(ctx->xy32.reserve(8 * (size_t)N));
+    HIPCHK(ctx->hxy32.reserve(8 * (size_t)std::max<int64_t>(ctx->halo_total, 1)));
+    HIPCHK(ctx->rqp32a.reserve(sizeof(magk::Rqp32) * (size_t)N));
+    HIPCHK(ctx->rqp32b.reserve(sizeof(magk::Rqp32) * (size_t)N));
+    HIPCHK(ctx->x32.reserve(8 * (size_t)N));
+    HIPCHK(ctx->fpart.reserve(8 * 2 * 4 * (size_t)stride));
+    HIPCHK(ctx->fstate.reserve(sizeof(FusedState)));
+    magk::coords32(ctx->xyP.as<double>(), ctx->halo_g.as<int32_t>(), ctx->tile_hoff.as<int32_t>(), N, ctx->B, ctx->T,
+                   ctx->xy32.as<float>(), ctx->hxy32.as<float>(), s);
+    const int grid = magk::fused32_grid(ctx->B, ctx->cap, ctx->T);
+    HIPCHK(hipMemsetAsync(ctx->fpart.p, 0, 8 * 2 * 4 * (size_t)stride, s));
+    magk::fused32_init(ctx->bP.as<double2>(), ctx->rqp32a.as<magk::Rqp32>(), ctx->rqp32b.as<magk::Rqp32>(),
+                       ctx->x32.as<float2>(), N, ctx->B, ctx->T, ctx->fpart.as<double>(), stride, grid, s);
+    magk::fused_setup(ctx->fpart.as<double>(), grid, stride, ctx->opt.stop_mode, ctx->opt.tol,
+                      (long long)ctx->opt.max_iter, ctx->fstate.as<FusedState>(), s);
+    HIPCHK(hipGetLastError());
+    const int G = ctx->opt.check_every;
+    const long long max_blocks = (long long)(ctx->opt.max_iter / G) + 3;
+    bool done = false;
+    int slot = 0;
+    for (long long blk = 0; blk < max_blocks && !done; ++blk) {
+        for (int i = 0; i < G; ++i) {
+            magk::Fused32Params P = {};
+            const int par = i & 1;
+            P.N = N;
+            P.T = ctx->T;
+            P.nPart = grid;
+            P.cap = ctx->cap;
+            P.par = par;
+            P.hist_len = ctx->opt.history_len;
+            P.xyP32 = ctx->xy32.as<float2>();
+            P.maskP = ctx->maskP.as<uint8_t>();
+            P.meta = ctx->tmeta.as<magk::TileMeta>();
+            P.ell16 = ctx->ell.as<uint32_t>();
+            P.halo_g = ctx->halo_g.as<int32_t>();
+            P.halo_xy32 = ctx->hxy32.as<float2>();
+            P.c0 = (float)(ctx->youngs * ctx->thick / (2.0 * (1.0 - ctx->nu * ctx->nu)));
+            P.nu = (float)ctx->nu;
+            P.h = (float)((1.0 - ctx->nu) / 2.0);
+            P.in = (par ? ctx->rqp32b : ctx->rqp32a).as<magk::Rqp32>();
+            P.out = (par ? ctx->rqp32a : ctx->rqp32b).as<magk::Rqp32>();
+            P.x = ctx->x32.as<float2>();
+            P.part_in = ctx->fpart.as<double>() + (size_t)par * 4 * stride;
+            P.part_out = ctx->fpart.as<double>() + (size_t)(par ^ 1) * 4 * stride;
+            P.part_stride = stride;
+            P.st = ctx->fstate.as<FusedState>();
+            P.hist = ctx->hist.as<double>();
+            magk::fused32_launch(P, ctx->B, grid, s);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&ctx->h_fstate[slot], ctx->fstate.p, sizeof(FusedState), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(ctx->evPoll[slot], s));
+        if (blk >= 1) {
+            HIPCHK(hipEventSynchronize(ctx->evPoll[slot ^ 1]));
+            done = ctx->h_fstate[slot ^ 1].done != 0;
+        }
+        slot ^= 1;
+    }
+    magk::x32_to_f64(ctx->x32.as<float2>(), N, ctx->x.as<double2>(), s);
+    HIPCHK(hipMemcpyAsync(&ctx->h_fstate[2], ctx->fstate.p, sizeof(FusedState), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const FusedState &st = ctx->h_fstate[2];
+    ctx->stats.iterations = st.iterations;
+    ctx->stats.final_cost = st.final_cost;
+    ctx->stats.rhs_norm = std::sqrt(st.bb);
+    ctx->stats.converged = st.converged;
+    ctx->stats.breakdown = st.breakdown;
+    return MAG_OK;
+}
+
 double ev_ms(hipEvent_t a, hipEvent_t b)
 {
     float ms = 0.f;
@@ -970,6 +1050,7 @@ void mag_default_options(mag_options *o)
     o->verbose = 0;
     o->op_variant = 0;
     o->cg_variant = 1;
+    o->precision = 0;
 }
 
 mag_ctx *mag_create(const mag_options *opt)
@@ -1026,7 +1107,7 @@ void mag_destroy(mag_ctx *ctx)
                           &ctx->val_ff, &ctx->b_ff, &ctx->rp_full, &ctx->col_full, &ctx->x, &ctx->r, &ctx->p0,
                           &ctx->p1, &ctx->q, &ctx->bP, &ctx->tmpP, &ctx->partRR, &ctx->partPQ, &ctx->state,
                           &ctx->hist, &ctx->u, &ctx->f, &ctx->stress, &ctx->rqp0, &ctx->rqp1, &ctx->fpart, &ctx->fstate,
-                          &ctx->tmeta, &ctx->comm_f};
+                          &ctx->tmeta, &ctx->comm_f, &ctx->xy32, &ctx->hxy32, &ctx->rqp32a, &ctx->rqp32b, &ctx->x32};
         for (DevBuf *b : bufs) b->release();
         if (ctx->h_state) (void)hipHostFree(ctx->h_state);
         if (ctx->h_fstate) (void)hipHostFree(ctx->h_fstate);
@@ -1154,7 +1235,10 @@ int mag_run(mag_ctx *ctx)
     HIPCHK(ctx->f.reserve(16 * (size_t)N));
     HIPCHK(ctx->stress.reserve(8 * (size_t)E));
     const bool csr_op = ctx->opt.cg_operator == MAG_OP_CSR;
-    if (int rc = csr_op ? cg_phase_csr(ctx) : (ctx->fused ? cg_phase_fused(ctx) : cg_phase(ctx))) return rc;
+    const bool f32 = ctx->opt.precision == 1;
+    if (int rc = csr_op ? cg_phase_csr(ctx)
+                        : (f32 ? cg_phase_fused32(ctx) : (ctx->fused ? cg_phase_fused(ctx) : cg_phase(ctx))))
+        return rc;
     HIPCHK(hipEventRecord(ctx->ev[6], s));
     if (ctx->opt.verbose)
         printf("info: finished conjugate gradient approximation in %lld iterations\n", (long long)st.iterations);

@@ -251,6 +251,39 @@ void fused_pack(const double *part, int nPart, int32_t stride, const Rqp *v, con
 void fused_unpack(const double *buf, const int32_t *iface, int32_t n_iface, int32_t own0, int32_t own1, Rqp *v,
                   hipStream_t s);
 
+// ---- fp32 leg of BASELINE config 5 (fp64 vs fp32 CG tolerance sweep): the fused iteration with the CG state, the
+// operator arithmetic and TILE-RELATIVE coordinates in fp32; dot products accumulate in fp64 ----
+struct Rqp32 {
+    float2 r, q, p;
+};
+struct Fused32Params {
+    int64_t N;
+    int32_t T, nPart, cap, par, hist_len, pad;
+    const float2 *xyP32;     // owned nodes, relative to their tile's first node
+    const uint8_t *maskP;
+    const TileMeta *meta;
+    const uint32_t *ell16;
+    const int32_t *halo_g;
+    const float2 *halo_xy32; // halo nodes, relative to the READING tile's first node
+    float c0, nu, h;
+    const Rqp32 *in;
+    Rqp32 *out;
+    float2 *x;
+    const double *part_in;
+    double *part_out;
+    int32_t part_stride;
+    int32_t pad2;
+    FusedState *st;
+    double *hist;
+};
+void coords32(const double *xyP, const int32_t *halo_g, const int32_t *tile_hoff, int64_t N, int32_t B, int32_t T,
+              float *xyP32, float *halo_xy32, hipStream_t s);
+void fused32_launch(const Fused32Params &P, int32_t B, int32_t grid, hipStream_t s);
+int fused32_grid(int32_t B, int32_t cap, int32_t tiles);
+void fused32_init(const double2 *bP, Rqp32 *in, Rqp32 *out, float2 *x, int64_t N, int32_t B, int32_t T, double *part,
+                  int32_t stride, int32_t grid, hipStream_t s);
+void x32_to_f64(const float2 *x32, int64_t N, double2 *x, hipStream_t s);
+
 int cg_grid(int32_t T);
 // operator kernel, B in {256,512,1024}; cg_mode: p = -r + beta*pprev fused, writes pnew, q, partPQ
 void op_launch(const OpParams &P, int32_t B, bool cg_mode, hipStream_t s);
