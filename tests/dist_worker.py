@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--mode", default="callback")
     ap.add_argument("--mesh", type=int, default=96)
     ap.add_argument("--variant", type=int, default=1)
+    ap.add_argument("--tile", type=int, default=256)
+    ap.add_argument("--stacked", type=int, default=0, help="bench.py's weak-scaling geometry: plate-with-hole stacked N times")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -30,11 +32,17 @@ def main():
     from magnetite_amd import Context, meshgen
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    prob = meshgen.config_fixed_left_pull_right(meshgen.shuffle(meshgen.plate_with_holes(a.mesh, 2 * a.mesh, 1.0, 2.0), 3))
+    if a.stacked:
+        holes = [(0.5, (k + 0.5) / a.stacked, 0.15) for k in range(a.stacked)]
+        prob = meshgen.config_fixed_left_pull_right(
+            meshgen.plate_with_holes(a.mesh, a.mesh * a.stacked, 1.0, float(a.stacked), holes=holes))
+    else:
+        prob = meshgen.config_fixed_left_pull_right(
+            meshgen.shuffle(meshgen.plate_with_holes(a.mesh, 2 * a.mesh, 1.0, 2.0), 3))
     if a.mode == "rccl1":
         os.environ["MAG_TUNE_FORCE_DIST"] = "1"
         dist.init_process_group("gloo", rank=0, world_size=1, init_method="tcp://127.0.0.1:29533")
-        with Context(device=0, tile_nodes=256, cg_variant=a.variant) as c:
+        with Context(device=0, tile_nodes=a.tile, cg_variant=a.variant) as c:
             c.init_rccl_from_torch(dist, 0, 1)
             out = c.solve(prob)
     else:
@@ -44,14 +52,14 @@ def main():
             t = torch.from_numpy(arr)
             dist.all_reduce(t)
 
-        with Context(device=0, tile_nodes=256, cg_variant=a.variant) as c:
+        with Context(device=0, tile_nodes=a.tile, cg_variant=a.variant) as c:
             c.init_callback(allreduce, rank, world)
             out = c.solve(prob)
     ref = oracle.run(prob.xy_flat, prob.conn_flat, prob.u_known, prob.u_in, prob.f_in, prob.youngs_modulus,
                      prob.poisson_ratio, prob.part_thickness, path="sparse")
     err = np.linalg.norm(out["u"] - ref["u"]) / np.linalg.norm(ref["u"])
     os.environ.pop("MAG_TUNE_FORCE_DIST", None)
-    with Context(device=0, tile_nodes=256, cg_variant=a.variant) as c1:
+    with Context(device=0, tile_nodes=a.tile, cg_variant=a.variant) as c1:
         single = c1.solve(prob)
     err1 = np.linalg.norm(out["u"] - single["u"]) / np.linalg.norm(single["u"])
     print(f"rank {rank}/{world} mode={a.mode} iters={out['iterations']} (single {single['iterations']}, oracle "

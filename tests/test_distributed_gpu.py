@@ -10,9 +10,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
-def launch(nproc, mode, port, variant=1):
+def launch(nproc, mode, port, variant=1, extra=()):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER, "--mode", mode, "--variant", str(variant)]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER, "--mode", mode, "--variant", str(variant),
+           *extra]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
 
@@ -20,6 +21,13 @@ def launch(nproc, mode, port, variant=1):
 @pytest.mark.parametrize("nproc,variant", [(2, 1), (3, 1), (2, 0)])
 def test_ranks_sharing_one_gpu_through_gloo(built, nproc, variant):
     r = launch(nproc, "callback", 29540 + nproc + 10 * variant, variant)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_four_ranks_on_the_weak_scaling_geometry(built):
+    """bench.py --gpus 4's mesh (plate-with-hole stacked 4x along y) at reduced resolution, default tile size,
+    default CG variant: 4 ranks share the one GPU, collectives through gloo."""
+    r = launch(4, "callback", 29571, 1, ("--tile", "512", "--stacked", "4", "--mesh", "150"))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
 
 
