@@ -61,6 +61,8 @@ def lib():
         L.orc_spmv.argtypes = [C.c_void_p, dp, dp]
         L.orc_cg.restype = C.c_int64
         L.orc_cg.argtypes = [C.c_void_p, dp, C.c_int, C.c_double, C.c_int64, dp, dp, dp, C.c_int64]
+        L.orc_cg_parallel.restype = C.c_int64
+        L.orc_cg_parallel.argtypes = [C.c_void_p, dp, C.c_int, C.c_double, C.c_int64, dp, dp]
         L.orc_stress.argtypes = [C.c_int64, dp, ip, dp, C.c_double, C.c_double, dp]
         L.orc_assemble_sparse.restype = C.c_void_p
         L.orc_assemble_sparse.argtypes = [C.c_int64, C.c_int64, dp, ip, C.c_double, C.c_double, C.c_double]
@@ -199,6 +201,21 @@ def cg(A, b, stop_mode=STOP_RNORM, tol=TARGET_CG_COST, max_iter=MAX_CG_ITER, his
     hist = np.zeros(max(hist_len, 1))
     it = lib().orc_cg(A._h, _d(b), stop_mode, float(tol), int(max_iter), _d(x), C.byref(cost), _d(hist), hist_len)
     return x[:A.n], int(it), cost.value, hist[:min(hist_len, it)]
+
+
+def cg_parallel(A, b, stop_mode=STOP_RNORM, tol=TARGET_CG_COST, max_iter=MAX_CG_ITER, threads=None):
+    """All-cores variant (OpenMP).  threads=None keeps OMP_NUM_THREADS / the runtime default."""
+    if threads:
+        os.environ["OMP_NUM_THREADS"] = str(int(threads))
+        try:
+            C.CDLL("libgomp.so.1").omp_set_num_threads(int(threads))
+        except OSError:
+            pass
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.zeros(max(A.n, 1))
+    cost = C.c_double(0.0)
+    it = lib().orc_cg_parallel(A._h, _d(b), stop_mode, float(tol), int(max_iter), _d(x), C.byref(cost))
+    return x[:A.n], int(it), cost.value
 
 
 def stress(xy, conn, u, nu, youngs):

@@ -280,6 +280,61 @@ int64_t orc_cg(const orc_csr *A, const double *b, int stop_mode, double tol, int
     return it;
 }
 
+/* All-cores variant of the same CG ("also report an OpenMP variant on all host cores"): rows of the SpMV
+ * and the vector updates are split over threads, dot products are OpenMP reductions (summation order differs from
+ * argmin's sequential sums).  The reference itself is single-threaded; this exists only so the CPU baseline is not
+ * flattered by idle cores.  Returns iterations executed; x holds the last iterate. */
+int64_t orc_cg_parallel(const orc_csr *A, const double *b, int stop_mode, double tol, int64_t max_iter, double *x,
+                        double *final_cost)
+{
+    const int64_t n = A->n;
+    double *r = (double *)malloc(sizeof(double) * ((size_t)n + 1));
+    double *p = (double *)malloc(sizeof(double) * ((size_t)n + 1));
+    double *q = (double *)malloc(sizeof(double) * ((size_t)n + 1));
+    double rtr = 0.0, bb = 0.0;
+#pragma omp parallel for reduction(+ : rtr, bb) schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        x[i] = 0.0;
+        r[i] = -b[i];
+        p[i] = b[i];
+        rtr += b[i] * b[i];
+        bb += b[i] * b[i];
+    }
+    const double target = stop_mode == ORC_STOP_REL ? tol * sqrt(bb) : tol;
+    double cost = INFINITY;
+    int64_t it = 0;
+    if (rtr == 0.0) cost = 0.0;
+    while (it < max_iter && !(cost <= target)) {
+        double pq = 0.0;
+#pragma omp parallel for reduction(+ : pq) schedule(static)
+        for (int64_t i = 0; i < n; ++i) {
+            double s = 0.0;
+            for (int64_t k = A->rowptr[i]; k < A->rowptr[i + 1]; ++k) s += A->val[k] * p[A->col[k]];
+            q[i] = s;
+            pq += p[i] * s;
+        }
+        const double alpha = rtr / pq;
+        double rtr_n = 0.0;
+#pragma omp parallel for reduction(+ : rtr_n) schedule(static)
+        for (int64_t i = 0; i < n; ++i) {
+            x[i] = x[i] + alpha * p[i];
+            r[i] = r[i] + alpha * q[i];
+            rtr_n += r[i] * r[i];
+        }
+        const double beta = rtr_n / rtr;
+        rtr = rtr_n;
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < n; ++i) p[i] = r[i] * -1.0 + beta * p[i];
+        cost = (stop_mode == ORC_STOP_RNORM_SQ) ? fabs(rtr_n) : sqrt(rtr_n);
+        ++it;
+    }
+    if (final_cost) *final_cost = cost;
+    free(r);
+    free(p);
+    free(q);
+    return it;
+}
+
 /* --------------------------------------------------------- post-solve --- */
 
 /* solver.rs:496-535  compute_stress: sigma = (D*B)*u_e, scalar =

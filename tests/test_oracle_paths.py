@@ -116,6 +116,15 @@ def test_cg_restatement_semantics(built):
     assert it0 == 0 and c0 == 0.0 and not x0.any()
 
 
+def test_parallel_cg_variant_agrees(built):
+    p = CASES["hole_perturbed"]()
+    K = oracle.assemble_sparse(p.xy_flat, p.conn_flat, p.poisson_ratio, p.youngs_modulus, p.part_thickness)
+    A, b = oracle.reduce_system(K, p.u_known, p.u_in, p.f_in)
+    x, it, _, _ = oracle.cg(A, b)
+    xp, itp, cost = oracle.cg_parallel(A, b, threads=4)
+    assert abs(it - itp) <= 3 and cost <= 1e-4 and rel(xp, x) <= 1e-9
+
+
 def test_clockwise_mesh_same_displacements_for_displacement_loading(built):
     """K -> -K and b -> -b when every element is reversed and all loads are prescribed displacements."""
     a = run(meshgen.config_fixed_left_pull_right(meshgen.plate(8)), "dense")
