@@ -14,13 +14,20 @@
 // and the thread accumulates only ITS corner's force  f_a = t*A * B_a^T D B u_e
 // -- owner-computes, so there is no scatter, no atomic and no colouring pass,
 // and the summation order per node is fixed (ascending element index).
-// Corners owned by another tile are fetched from global memory (L2) and their
-// p is recomputed from r and p_prev, which are stable during the launch.
+// Corners owned by another tile (the tile's halo) are staged in LDS next to the
+// owned nodes (k_operator_lds, k_cg_fused*) or, when a tile's halo would not
+// fit, read from global memory (k_operator, the gather fallback); their p is
+// recomputed from their previous state, which is stable during the launch.
 //
-// Two launches per CG iteration; the two dot products are reduced in a fixed
-// order from <= kMaxGrid per-workgroup partials by every workgroup of the
-// NEXT launch (the kernel boundary is the grid-wide sync), so results are
-// bitwise reproducible run to run.
+// Kernels in this file, in the order they appear:
+//   k_operator / k_operator_lds   y = [M] K [M] v, or (CG mode) the operator launch of the two-launch iteration
+//   k_update                      r += alpha q, r.r          (two-launch iteration, cg_variant 0)
+//   k_csr_*                       the reference's literal iteration on K_ff in CSR (MAG_OP_CSR)
+//   k_cg_fused / k_cg_fused_dma   ONE launch per CG iteration (cg_variant 1, default; _dma = LDS-DMA staging)
+//   k_cg_fused32                  the same in fp32 (BASELINE config 5's sweep)
+// Dot products are reduced in a fixed order from <= kMaxGrid per-workgroup
+// partials by every workgroup of the NEXT launch (the kernel boundary is the
+// grid-wide sync), so results are bitwise reproducible run to run.
 #include <cstdlib>
 #include <cstring>
 

@@ -370,3 +370,32 @@ def test_fp32_leg_of_config5(built):
     with Context(device=0, stop_mode=MAG_STOP_REL, tol=1e-11) as c:
         f64 = c.solve(p)
     assert rel(f64["u"], ref["u"]) < rel(tight["u"], ref["u"])
+
+
+def test_pathological_hub_falls_back_to_the_gather_operator(built):
+    """One node shared by 3000 elements: the hub's tile needs far more halo nodes than fit its LDS image, so the
+    library must switch to the global-gather operator (and the two-launch iteration) by itself -- no error, same u."""
+    n = 3000
+    ang = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    ring1 = np.stack([np.cos(ang), np.sin(ang)], axis=1)
+    ring2 = 1.5 * ring1
+    xy = np.concatenate([[[0.0, 0.0]], ring1, ring2])
+    tri = [[0, 1 + k, 1 + (k + 1) % n] for k in range(n)]
+    tri += [[1 + k, 1 + n + k, 1 + n + (k + 1) % n] for k in range(n)]
+    tri += [[1 + k, 1 + n + (k + 1) % n, 1 + (k + 1) % n] for k in range(n)]
+    m = meshgen.shuffle(meshgen.Mesh(xy, np.array(tri, dtype=np.int32), "hub"), 1)
+    p = meshgen.apply_boundary_rules(m, [meshgen.BoundaryRule("hold", x_max=-1.2, ux=0.0, uy=0.0),
+                                         meshgen.BoundaryRule("pull", x_min=1.2, ux=0.01, fy=0.0)])
+    K = oracle.assemble_sparse(p.xy_flat, p.conn_flat, p.poisson_ratio, p.youngs_modulus, p.part_thickness)
+    A, b = oracle.reduce_system(K, p.u_known, p.u_in, p.f_in)
+    _, _, _, hist_ref = oracle.cg(A, b, max_iter=30, hist_len=30)
+    x = np.random.default_rng(8).standard_normal(K.n)
+    # (a 3000-valence node pads its tile's slot table to 3000 slots: correct but slow, so no run to convergence here)
+    for tile in (512, 256):
+        with Context(device=0, tile_nodes=tile, max_iter=30, history_len=30) as c:
+            out = c.solve(p, allow_not_converged=True)
+            hist = c.history(30)
+            y = c.apply_operator(x, masked=False)
+        assert out["max_tile_halo"] > 2016 - tile and out["lds_operator"] == 0 and out["iterations"] == 30
+        assert np.allclose(hist, hist_ref, rtol=1e-8)
+        assert rel(y, K.spmv(x)) < 1e-12
