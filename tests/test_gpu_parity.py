@@ -399,3 +399,36 @@ def test_pathological_hub_falls_back_to_the_gather_operator(built):
         assert out["max_tile_halo"] > 2016 - tile and out["lds_operator"] == 0 and out["iterations"] == 30
         assert np.allclose(hist, hist_ref, rtol=1e-8)
         assert rel(y, K.spmv(x)) < 1e-12
+
+
+def test_device_resident_inputs_and_outputs(built):
+    """mag_problem.memory / mag_result.memory = MAG_MEM_DEVICE: pointers into HBM owned by the caller (here torch)."""
+    import ctypes as C
+
+    import torch
+
+    from magnetite_amd import _lib
+    p = PROBLEMS["plate_shuffled"]
+    ref = oracle_run(p)
+    dev = torch.device("cuda", 0)
+    t = dict(xy=torch.from_numpy(p.xy_flat).to(dev), conn=torch.from_numpy(p.conn_flat).to(dev),
+             uk=torch.from_numpy(p.u_known).to(dev), ui=torch.from_numpy(p.u_in).to(dev),
+             fi=torch.from_numpy(p.f_in).to(dev))
+    N, E = p.mesh.num_nodes, p.mesh.num_elements
+    u = torch.empty(2 * N, dtype=torch.float64, device=dev)
+    f = torch.empty(2 * N, dtype=torch.float64, device=dev)
+    s = torch.empty(E, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    L = _lib.lib()
+    with Context(device=0) as c:
+        prob = _lib.Problem(N, E, t["xy"].data_ptr(), t["conn"].data_ptr(), t["uk"].data_ptr(), t["ui"].data_ptr(),
+                            t["fi"].data_ptr(), p.youngs_modulus, p.poisson_ratio, p.part_thickness,
+                            _lib.MAG_MEM_DEVICE, 0)
+        res = _lib.Result(u.data_ptr(), f.data_ptr(), s.data_ptr(), _lib.MAG_MEM_DEVICE, 0)
+        rc = L.mag_solve(c._h, C.byref(prob), C.byref(res))
+        assert rc == 0, L.mag_last_error(c._h)
+    torch.cuda.synchronize()
+    assert rel(u.cpu().numpy(), ref["u"]) <= TOL_U
+    k = p.u_known == 1
+    assert np.array_equal(f.cpu().numpy()[~k], p.f_in[~k])
+    assert np.isfinite(s.cpu().numpy()).all()
