@@ -402,33 +402,44 @@ def test_pathological_hub_falls_back_to_the_gather_operator(built):
 
 
 def test_device_resident_inputs_and_outputs(built):
-    """mag_problem.memory / mag_result.memory = MAG_MEM_DEVICE: pointers into HBM owned by the caller (here torch)."""
+    """mag_problem.memory / mag_result.memory = MAG_MEM_DEVICE: pointers into HBM owned by the caller (allocated here
+    with hipMalloc through ctypes -- no torch in this process, see bench.py on import order)."""
     import ctypes as C
 
-    import torch
-
     from magnetite_amd import _lib
+    L = _lib.lib()  # pulls in libamdhip64.so.7
+    hip = C.CDLL("libamdhip64.so.7")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    H2D, D2H = 1, 2
+
+    def to_dev(a):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), a.nbytes) == 0
+        assert hip.hipMemcpy(p, a.ctypes.data, a.nbytes, H2D) == 0
+        return p
+
+    def from_dev(p, n, dtype=np.float64):
+        out = np.empty(n, dtype=dtype)
+        assert hip.hipMemcpy(out.ctypes.data, p, out.nbytes, D2H) == 0
+        return out
+
     p = PROBLEMS["plate_shuffled"]
     ref = oracle_run(p)
-    dev = torch.device("cuda", 0)
-    t = dict(xy=torch.from_numpy(p.xy_flat).to(dev), conn=torch.from_numpy(p.conn_flat).to(dev),
-             uk=torch.from_numpy(p.u_known).to(dev), ui=torch.from_numpy(p.u_in).to(dev),
-             fi=torch.from_numpy(p.f_in).to(dev))
     N, E = p.mesh.num_nodes, p.mesh.num_elements
-    u = torch.empty(2 * N, dtype=torch.float64, device=dev)
-    f = torch.empty(2 * N, dtype=torch.float64, device=dev)
-    s = torch.empty(E, dtype=torch.float64, device=dev)
-    torch.cuda.synchronize()
-    L = _lib.lib()
     with Context(device=0) as c:
-        prob = _lib.Problem(N, E, t["xy"].data_ptr(), t["conn"].data_ptr(), t["uk"].data_ptr(), t["ui"].data_ptr(),
-                            t["fi"].data_ptr(), p.youngs_modulus, p.poisson_ratio, p.part_thickness,
+        bufs = [to_dev(a) for a in (p.xy_flat, p.conn_flat, p.u_known, p.u_in, p.f_in)]
+        outs = [to_dev(np.zeros(n)) for n in (2 * N, 2 * N, E)]
+        prob = _lib.Problem(N, E, *[b.value for b in bufs], p.youngs_modulus, p.poisson_ratio, p.part_thickness,
                             _lib.MAG_MEM_DEVICE, 0)
-        res = _lib.Result(u.data_ptr(), f.data_ptr(), s.data_ptr(), _lib.MAG_MEM_DEVICE, 0)
+        res = _lib.Result(*[o.value for o in outs], _lib.MAG_MEM_DEVICE, 0)
         rc = L.mag_solve(c._h, C.byref(prob), C.byref(res))
         assert rc == 0, L.mag_last_error(c._h)
-    torch.cuda.synchronize()
-    assert rel(u.cpu().numpy(), ref["u"]) <= TOL_U
+        u, f, s = from_dev(outs[0], 2 * N), from_dev(outs[1], 2 * N), from_dev(outs[2], E)
+        for b in bufs + outs:
+            hip.hipFree(b)
+    assert rel(u, ref["u"]) <= TOL_U
     k = p.u_known == 1
-    assert np.array_equal(f.cpu().numpy()[~k], p.f_in[~k])
-    assert np.isfinite(s.cpu().numpy()).all()
+    assert np.array_equal(f[~k], p.f_in[~k])
+    assert np.isfinite(s).all()
