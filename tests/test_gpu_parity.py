@@ -443,3 +443,47 @@ def test_device_resident_inputs_and_outputs(built):
     k = p.u_known == 1
     assert np.array_equal(f[~k], p.f_in[~k])
     assert np.isfinite(s).all()
+
+
+def _random_delaunay_problem(seed):
+    """Unstructured mesh: random points in a rectangle (plus a boundary frame) triangulated by Delaunay, random node
+    numbering, clamped strip on one side, a random mix of prescribed displacements / forces elsewhere."""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(seed)
+    lx, ly = rng.uniform(0.5, 3.0), rng.uniform(0.5, 3.0)
+    n = int(rng.integers(300, 2500))
+    k = int(np.sqrt(n) / 2) + 3
+    frame = np.concatenate([np.stack([np.linspace(0, lx, k), np.zeros(k)], 1), np.stack([np.linspace(0, lx, k), np.full(k, ly)], 1),
+                            np.stack([np.zeros(k), np.linspace(0, ly, k)], 1)[1:-1], np.stack([np.full(k, lx), np.linspace(0, ly, k)], 1)[1:-1]])
+    pts = np.concatenate([frame, rng.uniform([0.02 * lx, 0.02 * ly], [0.98 * lx, 0.98 * ly], size=(n, 2))])
+    tri = Delaunay(pts).simplices
+    a = pts[tri]
+    area = 0.5 * ((a[:, 1, 0] - a[:, 0, 0]) * (a[:, 2, 1] - a[:, 0, 1]) - (a[:, 2, 0] - a[:, 0, 0]) * (a[:, 1, 1] - a[:, 0, 1]))
+    tri = tri[np.abs(area) > 1e-7 * lx * ly]  # drop slivers on the frame
+    area = area[np.abs(area) > 1e-7 * lx * ly]
+    tri[area < 0] = tri[area < 0][:, ::-1]
+    m = meshgen.shuffle(meshgen.Mesh(pts, tri.astype(np.int32), f"delaunay{seed}"), seed)
+    rules = [meshgen.BoundaryRule("clamp", x_max=0.05 * lx, ux=0.0, uy=0.0)]
+    if seed % 2:
+        rules.append(meshgen.BoundaryRule("pull", x_min=0.95 * lx, ux=rng.uniform(-1e-3, 1e-3), fy=rng.uniform(-50, 50)))
+    else:
+        rules.append(meshgen.BoundaryRule("push", y_min=0.9 * ly, x_min=0.5 * lx, fx=rng.uniform(-100, 100), uy=rng.uniform(-1e-3, 1e-3)))
+    rules.append(meshgen.BoundaryRule("spot", x_min=0.4 * lx, x_max=0.6 * lx, y_min=0.4 * ly, y_max=0.6 * ly,
+                                      fx=rng.uniform(-1e4, 1e4), fy=rng.uniform(-1e4, 1e4)))
+    return meshgen.apply_boundary_rules(m, rules, youngs_modulus=10.0 ** rng.uniform(6, 11),
+                                        poisson_ratio=rng.uniform(0.05, 0.45), part_thickness=rng.uniform(0.1, 2.0))
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_random_unstructured_meshes(built, seed):
+    p = _random_delaunay_problem(seed)
+    ref = oracle_run(p)
+    with Context(device=0, tile_nodes=(256, 512, 1024)[seed % 3], cg_variant=1 if seed % 4 else 0) as c:
+        c.upload_problem(p)
+        assert np.array_equal(c.element_stiffness(), oracle.element_stiffness_all(
+            p.xy_flat, p.conn_flat, p.poisson_ratio, p.youngs_modulus, p.part_thickness))
+        out = c.solve(p)
+    assert out["converged"] == 1
+    assert rel(out["u"], ref["u"]) <= TOL_U
+    # near the absolute threshold the residual wanders at round-off level: a few per cent of slack on the count
+    assert abs(out["iterations"] - ref["iterations"]) <= max(5, ref["iterations"] // 20)
