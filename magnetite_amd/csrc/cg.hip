@@ -499,10 +499,31 @@ __global__ void __launch_bounds__(B) k_operator_lds(const OpParams P)
 
 size_t op_lds_bytes(int32_t cap, int32_t B) { return (size_t)cap * 32 + (size_t)(B / 64) * 8 + 16; }
 
+// plain SpMV launches need no dot partials, so their grid is free: one persistent round (all workgroups co-resident)
+static int op_plain_grid(int32_t B, int32_t cap, int32_t tiles)
+{
+    int dev = 0, cus = 256, per_cu = 1;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const size_t lds = op_lds_bytes(cap, B);
+    hipError_t e;
+    if (B == 256)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_operator_lds<256, false, false>, 256, lds);
+    else if (B == 1024)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_operator_lds<1024, false, false>, 1024, lds);
+    else
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_operator_lds<512, false, false>, 512, lds);
+    if (e != hipSuccess || per_cu < 1) per_cu = 1;
+    long g = (long)per_cu * cus;
+    if (g > tiles) g = tiles;
+    return g < 1 ? 1 : (int)g;
+}
+
 void op_launch(const OpParams &P, int32_t B, bool cg_mode, hipStream_t s)
 {
-    const int grid = cg_grid(P.t1 - P.t0);
+    int grid = cg_grid(P.t1 - P.t0);
     if (P.ell16) {
+        if (!cg_mode) grid = op_plain_grid(B, P.cap, P.t1 - P.t0);
         const size_t lds = op_lds_bytes(P.cap, B);
 #define MAG_OPL(BB)                                                       \
     if (!cg_mode)                                                         \
