@@ -164,8 +164,10 @@ def main():
         spmv_bytes = 12.0 * Eloc + 50.0 * Nloc          # matrix-free SpMV
         iter_bytes = 12.0 * Eloc + 242.0 * Nloc         # full CG iteration (SpMV + 2 dots + 3 axpy)
         fused = args.cg_variant == 1
-        kernel_bytes = iter_bytes if fused else spmv_bytes
+        kernel_bytes = iter_bytes if fused else (12.0 * Eloc + 50.0 * Nloc)
         achieved = kernel_bytes / (ms_op * 1e-3) / 1e9
+        # mag_time_spmv applies the plain operator to the WHOLE mesh on every rank (it is not partitioned)
+        spmv_bytes = 12.0 * E + 50.0 * N
         spmv_gbs = spmv_bytes / (ms_spmv * 1e-3) / 1e9
         asm_ms = st["ms_element"] + st["ms_assemble"] + st["ms_bc"]
         traffic, traffic_src = None, None
