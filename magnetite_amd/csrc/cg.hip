@@ -113,6 +113,35 @@ __device__ inline void corner_force(const double2 ca, const double2 pa, const do
     fy += w * (ga * sy + ba * tq);
 }
 
+// State machine of the two-launch iteration (operator launch): judge iterate k from its exact r.r, record the verdict,
+// derive beta.  Returns 0 to go on, 1 when the solve is over (x still lacks alpha_{k-1} p_{k-1}: the caller applies it
+// unless `broke`).
+__device__ inline int cg_step(CgState *st, long long k, double rr, double rrh0, double rrh1, double *hist, int hist_len,
+                              double &beta, bool &broke)
+{
+    const double cost = st->stop_mode == 1 ? fabs(rr) : sqrt(rr);
+    const bool finished = (k >= 1) && (cost <= st->target);
+    broke = !(fabs(rr) <= 1.79769313486231570e308); // NaN or inf
+    const bool maxed = k >= st->max_iter;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (k >= 1 && k - 1 < hist_len) hist[k - 1] = cost;
+        if (finished || broke || maxed) {
+            st->iterations = k;
+            st->final_cost = cost;
+            st->converged = finished ? 1 : 0;
+            st->breakdown = broke ? 1 : 0;
+            st->done = 1;
+        } else {
+            st->rr_hist[k & 1] = rr;
+            st->iterB = k;
+        }
+    }
+    if (finished || broke || maxed) return 1;
+    const double rr_prev = (k == 0) ? rr : ((k & 1) ? rrh0 : rrh1);
+    beta = rr / rr_prev;
+    return 0;
+}
+
 // ------------------------------------------------------ operator kernel ---
 template <int B, bool CG>
 __global__ void __launch_bounds__(B) k_operator(const OpParams P)
@@ -130,24 +159,8 @@ __global__ void __launch_bounds__(B) k_operator(const OpParams P)
         const double rrh0 = st->rr_hist[0], rrh1 = st->rr_hist[1];
         const double rr = sum_partials<B>(P.partRR, P.nPart, s_red);
         if (was_done) return;
-        const double cost = st->stop_mode == 1 ? fabs(rr) : sqrt(rr);
-        const bool finished = (k >= 1) && (cost <= st->target);
-        const bool broke = !(fabs(rr) <= 1.79769313486231570e308); // NaN or inf
-        const bool maxed = k >= st->max_iter;
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            if (k >= 1 && k - 1 < P.hist_len) P.hist[k - 1] = cost;
-            if (finished || broke || maxed) {
-                st->iterations = k;
-                st->final_cost = cost;
-                st->converged = finished ? 1 : 0;
-                st->breakdown = broke ? 1 : 0;
-                st->done = 1;
-            } else {
-                st->rr_hist[k & 1] = rr;
-                st->iterB = k;
-            }
-        }
-        if (finished || broke || maxed) {
+        bool broke = false;
+        if (cg_step(st, k, rr, rrh0, rrh1, P.hist, P.hist_len, beta, broke)) {
             if (!broke) {
                 for (int32_t t = P.t0 + blockIdx.x; t < P.t1; t += gridDim.x) {
                     const int64_t nd = (int64_t)t * B + threadIdx.x;
@@ -162,8 +175,6 @@ __global__ void __launch_bounds__(B) k_operator(const OpParams P)
             }
             return;
         }
-        const double rr_prev = (k == 0) ? rr : ((k & 1) ? rrh0 : rrh1);
-        beta = rr / rr_prev;
     }
 
     const double c0 = P.c0, nu = P.nu, h = P.h;
@@ -335,17 +346,14 @@ __global__ void __launch_bounds__(B) k_operator_lds(const OpParams P)
 
     // the whole CG state line is read before anything waits, together with the first tile's operands
     CgState *st = P.st;
-    long long k = 0, max_iter = 0;
-    int was_done = 0, stop_mode = 0;
-    double rrh0 = 0.0, rrh1 = 0.0, target = 0.0, alpha = 0.0;
+    long long k = 0;
+    int was_done = 0;
+    double rrh0 = 0.0, rrh1 = 0.0, alpha = 0.0;
     if (CG) {
         k = st->iterA;
         was_done = st->done;
         rrh0 = st->rr_hist[0];
         rrh1 = st->rr_hist[1];
-        target = st->target;
-        max_iter = st->max_iter;
-        stop_mode = st->stop_mode;
         alpha = st->alpha_last;
     }
     load_tile(P.t0 + blockIdx.x);
@@ -354,24 +362,8 @@ __global__ void __launch_bounds__(B) k_operator_lds(const OpParams P)
     if (CG) {
         const double rr = sum_partials<B>(P.partRR, P.nPart, s_red);
         if (was_done) return;
-        const double cost = stop_mode == 1 ? fabs(rr) : sqrt(rr);
-        const bool finished = (k >= 1) && (cost <= target);
-        const bool broke = !(fabs(rr) <= 1.79769313486231570e308);
-        const bool maxed = k >= max_iter;
-        if (blockIdx.x == 0 && tid == 0) {
-            if (k >= 1 && k - 1 < P.hist_len) P.hist[k - 1] = cost;
-            if (finished || broke || maxed) {
-                st->iterations = k;
-                st->final_cost = cost;
-                st->converged = finished ? 1 : 0;
-                st->breakdown = broke ? 1 : 0;
-                st->done = 1;
-            } else {
-                st->rr_hist[k & 1] = rr;
-                st->iterB = k;
-            }
-        }
-        if (finished || broke || maxed) {
+        bool broke = false;
+        if (cg_step(st, k, rr, rrh0, rrh1, P.hist, P.hist_len, beta, broke)) {
             // x still lacks the last step alpha_{k-1} p_{k-1} (the update is folded into this kernel)
             if (!broke) {
                 for (int32_t t = P.t0 + blockIdx.x; t < P.t1; t += gridDim.x) {
@@ -387,8 +379,6 @@ __global__ void __launch_bounds__(B) k_operator_lds(const OpParams P)
             }
             return;
         }
-        const double rr_prev = (k == 0) ? rr : ((k & 1) ? rrh0 : rrh1);
-        beta = rr / rr_prev;
     }
 
     const double c0 = P.c0, nu = P.nu, h = P.h;
@@ -768,26 +758,9 @@ __global__ void __launch_bounds__(256) k_csr_p(const CsrCgParams P)
     const double rrh0 = st->rr_hist[0], rrh1 = st->rr_hist[1];
     const double rr = sum_partials<256>(P.partRR, P.nPart, s_red);
     if (was_done) return;
-    const double cost = st->stop_mode == 1 ? fabs(rr) : sqrt(rr);
-    const bool finished = (k >= 1) && (cost <= st->target);
-    const bool broke = !(fabs(rr) <= 1.79769313486231570e308);
-    const bool maxed = k >= st->max_iter;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (k >= 1 && k - 1 < P.hist_len) P.hist[k - 1] = cost;
-        if (finished || broke || maxed) {
-            st->iterations = k;
-            st->final_cost = cost;
-            st->converged = finished ? 1 : 0;
-            st->breakdown = broke ? 1 : 0;
-            st->done = 1;
-        } else {
-            st->rr_hist[k & 1] = rr;
-            st->iterB = k;
-        }
-    }
-    const bool stop = finished || broke || maxed;
-    const double rr_prev = (k == 0) ? rr : ((k & 1) ? rrh0 : rrh1);
-    const double beta = rr / rr_prev;
+    bool broke = false;
+    double beta = 0.0;
+    const bool stop = cg_step(st, k, rr, rrh0, rrh1, P.hist, P.hist_len, beta, broke) != 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < P.n; i += (int64_t)gridDim.x * 256) {
         const double pp = P.pprev[i];
         if (!broke) P.x[i] += alpha * pp; // x += alpha_{k-1} p_{k-1}
@@ -892,6 +865,36 @@ void expand_free(const double *xf, const int32_t *fidx, const uint8_t *u_known, 
 // its error does not accumulate (one-step relative error ~ eps * |r_{j-1}|^2 / |r_j|^2); alpha, the stop test and
 // the reported cost all use the true r.r of the iterate, available one launch later.  Owner-computes as in
 // k_operator_lds; a tile recomputes r_j and p_j of its halo nodes from their previous record.
+// State machine shared by the fused iteration kernels: judge iterate j-1 from its exact dots S (identical in every
+// workgroup), let workgroup 0 record the verdict, and derive this launch's alpha and beta.  Returns false when the
+// solve is over (converged / iteration cap / non-finite residual): x and r of iterate j-1 are then already in place.
+__device__ inline bool fused_step(FusedState *st, int par, long long j, double target, long long max_iter, int stop_mode,
+                                  const double (&S)[4], double *hist, int hist_len, double &alpha, double &beta)
+{
+    const double rr = S[0]; // |r_{j-1}|^2, exact
+    const double cost = stop_mode == 1 ? fabs(rr) : sqrt(rr);
+    const long long it_done = j - 1; // argmin iterations completed when this launch starts
+    const bool finished = (it_done >= 1) && (cost <= target);
+    const bool broke = !(fabs(rr) <= 1.79769313486231570e308);
+    const bool maxed = it_done >= max_iter;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (it_done >= 1 && it_done - 1 < hist_len) hist[it_done - 1] = cost;
+        if (finished || broke || maxed) {
+            st->iterations = it_done < 0 ? 0 : it_done;
+            st->final_cost = cost;
+            st->converged = finished ? 1 : 0;
+            st->breakdown = broke ? 1 : 0;
+            st->done = 1;
+        } else {
+            st->jslot[par ^ 1] = j + 1;
+        }
+    }
+    if (finished || broke || maxed) return false;
+    alpha = rr / S[1];
+    beta = (rr + 2.0 * alpha * S[2] + alpha * alpha * S[3]) / rr;
+    return true;
+}
+
 template <int B>
 __device__ inline void block_sum4(double (&v)[4], double *s_red)
 {
@@ -982,28 +985,8 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
     }
     block_sum4<B>(S, s_red);
     if (was_done) return;
-    const double rr = S[0]; // |r_{j-1}|^2, exact
-    const double cost = stop_mode == 1 ? fabs(rr) : sqrt(rr);
-    const long long it_done = j - 1; // argmin iterations completed when this launch starts
-    const bool finished = (it_done >= 1) && (cost <= target);
-    const bool broke = !(fabs(rr) <= 1.79769313486231570e308);
-    const bool maxed = it_done >= max_iter;
-    if (blockIdx.x == 0 && tid == 0) {
-        if (it_done >= 1 && it_done - 1 < P.hist_len) P.hist[it_done - 1] = cost;
-        if (finished || broke || maxed) {
-            st->iterations = it_done < 0 ? 0 : it_done;
-            st->final_cost = cost;
-            st->converged = finished ? 1 : 0;
-            st->breakdown = broke ? 1 : 0;
-            st->done = 1;
-        } else {
-            st->jslot[P.par ^ 1] = j + 1;
-        }
-    }
-    if (finished || broke || maxed) return; // x, r of iterate j-1 are already in place
-    const double alpha = rr / S[1];
-    const double rr_next = rr + 2.0 * alpha * S[2] + alpha * alpha * S[3];
-    const double beta = rr_next / rr;
+    double alpha = 0.0, beta = 0.0;
+    if (!fused_step(st, P.par, j, target, max_iter, stop_mode, S, P.hist, P.hist_len, alpha, beta)) return;
 
     const double c0 = P.c0, nu = P.nu, h = P.h;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1181,28 +1164,8 @@ __global__ void __launch_bounds__(B) k_cg_fused_dma(const FusedParams P)
     }
     block_sum4<B>(S, s_red);
     if (was_done) return;
-    const double rr = S[0]; // |r_{j-1}|^2, exact
-    const double cost = stop_mode == 1 ? fabs(rr) : sqrt(rr);
-    const long long it_done = j - 1; // argmin iterations completed when this launch starts
-    const bool finished = (it_done >= 1) && (cost <= target);
-    const bool broke = !(fabs(rr) <= 1.79769313486231570e308);
-    const bool maxed = it_done >= max_iter;
-    if (blockIdx.x == 0 && tid == 0) {
-        if (it_done >= 1 && it_done - 1 < P.hist_len) P.hist[it_done - 1] = cost;
-        if (finished || broke || maxed) {
-            st->iterations = it_done < 0 ? 0 : it_done;
-            st->final_cost = cost;
-            st->converged = finished ? 1 : 0;
-            st->breakdown = broke ? 1 : 0;
-            st->done = 1;
-        } else {
-            st->jslot[P.par ^ 1] = j + 1;
-        }
-    }
-    if (finished || broke || maxed) return; // x, r of iterate j-1 are already in place
-    const double alpha = rr / S[1];
-    const double rr_next = rr + 2.0 * alpha * S[2] + alpha * alpha * S[3];
-    const double beta = rr_next / rr;
+    double alpha = 0.0, beta = 0.0;
+    if (!fused_step(st, P.par, j, target, max_iter, stop_mode, S, P.hist, P.hist_len, alpha, beta)) return;
 
     const double c0 = P.c0, nu = P.nu, h = P.h;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1599,28 +1562,9 @@ __global__ void __launch_bounds__(B) k_cg_fused32(const Fused32Params P)
     }
     block_sum4<B>(S, s_red);
     if (was_done) return;
-    const double rr = S[0];
-    const double cost = stop_mode == 1 ? fabs(rr) : sqrt(rr);
-    const long long it_done = j - 1;
-    const bool finished = (it_done >= 1) && (cost <= target);
-    const bool broke = !(fabs(rr) <= 1.79769313486231570e308);
-    const bool maxed = it_done >= max_iter;
-    if (blockIdx.x == 0 && tid == 0) {
-        if (it_done >= 1 && it_done - 1 < P.hist_len) P.hist[it_done - 1] = cost;
-        if (finished || broke || maxed) {
-            st->iterations = it_done < 0 ? 0 : it_done;
-            st->final_cost = cost;
-            st->converged = finished ? 1 : 0;
-            st->breakdown = broke ? 1 : 0;
-            st->done = 1;
-        } else {
-            st->jslot[P.par ^ 1] = j + 1;
-        }
-    }
-    if (finished || broke || maxed) return;
-    const double alpha_d = rr / S[1];
-    const float alpha = (float)alpha_d;
-    const float beta = (float)((rr + 2.0 * alpha_d * S[2] + alpha_d * alpha_d * S[3]) / rr);
+    double alpha_d = 0.0, beta_d = 0.0;
+    if (!fused_step(st, P.par, j, target, max_iter, stop_mode, S, P.hist, P.hist_len, alpha_d, beta_d)) return;
+    const float alpha = (float)alpha_d, beta = (float)beta_d;
 
     const float c0 = P.c0, nu = P.nu, h = P.h;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
