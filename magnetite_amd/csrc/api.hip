@@ -92,7 +92,7 @@ struct mag_ctx {
 
     // CSR of K (caller numbering)
     int64_t nb = 0;
-    DevBuf pk0, pk1, pv0, pv1, head, blk, rowcnt, seg_start, bptr, bcol, kval, ke;
+    DevBuf pk0, pk1, pv0, pv1, head, blk, rowcnt, seg_start, bptr, brow, bcol, kval, ke;
     // reduced system scratch
     DevBuf isfree, fidx, rcnt, rowoff, rp_ff, col_ff, val_ff, b_ff, rp_full, col_full;
     int64_t nf = 0, nz_ff = 0;
@@ -392,11 +392,13 @@ int csr_symbolic(mag_ctx *ctx)
     if (4 * nb >= (int64_t(1) << 31)) return fail(ctx, MAG_ERR_TOO_LARGE, "nnz of K (%lld) exceeds int32", (long long)(4 * nb));
     ctx->nb = nb;
     HIPCHK(ctx->seg_start.reserve(4 * ((size_t)nb + 1)));
+    HIPCHK(ctx->brow.reserve(4 * (size_t)nb));
     HIPCHK(ctx->bcol.reserve(4 * (size_t)nb));
     HIPCHK(ctx->kval.reserve(8 * 4 * (size_t)nb));
     HIPCHK(hipMemsetAsync(ctx->rowcnt.p, 0, 4 * ((size_t)N + 1), s));
     magk::csr_segments(ctx->pk1.as<uint64_t>(), ctx->head.as<int32_t>(), ctx->blk.as<int32_t>(), n9,
-                       ctx->seg_start.as<int32_t>(), ctx->bcol.as<int32_t>(), ctx->rowcnt.as<int32_t>(), s);
+                       ctx->seg_start.as<int32_t>(), ctx->brow.as<int32_t>(), ctx->bcol.as<int32_t>(),
+                       ctx->rowcnt.as<int32_t>(), s);
     if (int rc = scan_i32(ctx, ctx->rowcnt.as<int32_t>(), ctx->bptr.as<int32_t>(), (size_t)N + 1)) return rc;
     HIPCHK(hipGetLastError());
     return MAG_OK;
@@ -411,10 +413,20 @@ int element_phase(mag_ctx *ctx)
     return MAG_OK;
 }
 
+// numeric assembly, atomic-free.  Default: fused row assembly (no K_e buffer).  MAG_TUNE_KE_BUFFER=1 keeps the
+// two-step form (K_e for every element, then a gather over the sorted pairs) for A/B; both are bit-identical.
 int gather_phase(mag_ctx *ctx)
 {
-    magk::assemble_gather(ctx->pk1.as<uint64_t>(), ctx->pv1.as<uint32_t>(), ctx->seg_start.as<int32_t>(), ctx->nb,
-                          ctx->bptr.as<int32_t>(), ctx->ke.as<double>(), ctx->kval.as<double>(), ctx->stream);
+    if (getenv("MAG_TUNE_KE_BUFFER")) {
+        if (int rc = element_phase(ctx)) return rc;
+        magk::assemble_gather(ctx->pk1.as<uint64_t>(), ctx->pv1.as<uint32_t>(), ctx->seg_start.as<int32_t>(), ctx->nb,
+                              ctx->bptr.as<int32_t>(), ctx->ke.as<double>(), ctx->kval.as<double>(), ctx->stream);
+    } else {
+        magk::assemble_rows(ctx->brow.as<int32_t>(), ctx->bcol.as<int32_t>(), ctx->bptr.as<int32_t>(), ctx->nb,
+                            ctx->inc_off.as<int32_t>(), ctx->inc.as<uint32_t>(), ctx->iperm.as<int32_t>(),
+                            ctx->conn.as<int32_t>(), ctx->xy.as<double>(), ctx->nu, ctx->youngs, ctx->thick,
+                            ctx->kval.as<double>(), ctx->stream);
+    }
     HIPCHK(hipGetLastError());
     return MAG_OK;
 }
@@ -424,7 +436,6 @@ int ensure_csr(mag_ctx *ctx)
     if (ctx->have_csr) return MAG_OK;
     if (int rc = ensure_order(ctx)) return rc; // validates conn
     if (int rc = csr_symbolic(ctx)) return rc;
-    if (int rc = element_phase(ctx)) return rc;
     if (int rc = gather_phase(ctx)) return rc;
     ctx->have_csr = true;
     return MAG_OK;
@@ -1102,7 +1113,7 @@ void mag_destroy(mag_ctx *ctx)
                           &ctx->maskP, &ctx->deg, &ctx->inc_off, &ctx->inc, &ctx->tile_deg, &ctx->tile_cnt,
                           &ctx->tile_off, &ctx->ell, &ctx->hcnt, &ctx->hoffn, &ctx->hk0, &ctx->hk1, &ctx->halo_g, &ctx->halo_xy,
                           &ctx->tile_hcnt, &ctx->tile_hoff, &ctx->iface, &ctx->comm_pq, &ctx->comm_rr, &ctx->pk0, &ctx->pk1, &ctx->pv0, &ctx->pv1, &ctx->head,
-                          &ctx->blk, &ctx->rowcnt, &ctx->seg_start, &ctx->bptr, &ctx->bcol, &ctx->kval, &ctx->ke,
+                          &ctx->blk, &ctx->rowcnt, &ctx->seg_start, &ctx->bptr, &ctx->brow, &ctx->bcol, &ctx->kval, &ctx->ke,
                           &ctx->isfree, &ctx->fidx, &ctx->rcnt, &ctx->rowoff, &ctx->rp_ff, &ctx->col_ff,
                           &ctx->val_ff, &ctx->b_ff, &ctx->rp_full, &ctx->col_full, &ctx->x, &ctx->r, &ctx->p0,
                           &ctx->p1, &ctx->q, &ctx->bP, &ctx->tmpP, &ctx->partRR, &ctx->partPQ, &ctx->state,
@@ -1207,8 +1218,7 @@ int mag_run(mag_ctx *ctx)
     if (csr) {
         if (int rc = csr_symbolic(ctx)) return rc;
         HIPCHK(hipEventRecord(ctx->ev[2], s));
-        if (int rc = element_phase(ctx)) return rc;
-        HIPCHK(hipEventRecord(ctx->ev[3], s));
+        HIPCHK(hipEventRecord(ctx->ev[3], s)); // K_e is evaluated inside the row assembly (ms_element stays 0)
         if (ctx->opt.verbose) printf("info: building total stiffness matrix...\n");
         if (int rc = gather_phase(ctx)) return rc;
         ctx->have_csr = true;

@@ -126,6 +126,98 @@ void assemble_gather(const uint64_t *keys, const uint32_t *vals, const int32_t *
     k_assemble_gather<<<blocks_for(nb, 256), 256, 0, s>>>(keys, vals, seg_start, nb, bptr, ke, kval);
 }
 
+// solver.rs:263-278 + 290-331 fused and still atomic-free: one thread per (row node i, col node j) block of K walks
+// node i's incident elements in ascending element order (the reference's '+=' order) and, for every element that also
+// holds j, evaluates ONLY the 2x2 block K_e[2a..2a+1][2b..2b+1] -- each entry with exactly the operations
+// nalgebra performs for it ((B^T D) B, ascending-k sums from the first product, then * area * thickness), so the
+// result is bit-identical to scattering full K_e matrices.  No 288-byte-per-element K_e buffer is written or read.
+__device__ inline void ke_block(const double2 v0, const double2 v1, const double2 v2, int a, int b, const double *D,
+                                double thick, double &k00, double &k01, double &k10, double &k11)
+{
+    const double area = signed_area(v0.x, v0.y, v1.x, v1.y, v2.x, v2.y);
+    const double d = 2.0 * area;
+    const double b0 = v1.y - v2.y, b1 = v2.y - v0.y, b2 = v0.y - v1.y;
+    const double g0 = v2.x - v1.x, g1 = v0.x - v2.x, g2 = v1.x - v0.x;
+    const double z = 0.0 / d; // the structural zeros of B after `strain_displacement_mat /= 2.0 * area`
+    // columns 2c and 2c+1 of B (3 rows): (beta_c, 0, gamma_c)^T / d and (0, gamma_c, beta_c)^T / d
+    // (selects, not runtime-indexed arrays: those would live in scratch memory)
+    const double ba = (a == 0 ? b0 : (a == 1 ? b1 : b2)) / d, ga = (a == 0 ? g0 : (a == 1 ? g1 : g2)) / d;
+    const double bb = (b == 0 ? b0 : (b == 1 ? b1 : b2)) / d, gb = (b == 0 ? g0 : (b == 1 ? g1 : g2)) / d;
+    const double Bx_a[3] = {ba, z, ga}, By_a[3] = {z, ga, ba};
+    const double Bx_b[3] = {bb, z, gb}, By_b[3] = {z, gb, bb};
+    // rows 2a, 2a+1 of B^T D: M[r][m] = sum_k B[k][r] D[k][m]
+    double Mx[3], My[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        double s = Bx_a[0] * D[m];
+        s = s + Bx_a[1] * D[3 + m];
+        s = s + Bx_a[2] * D[6 + m];
+        Mx[m] = s;
+        double t = By_a[0] * D[m];
+        t = t + By_a[1] * D[3 + m];
+        t = t + By_a[2] * D[6 + m];
+        My[m] = t;
+    }
+    auto dot3 = [](const double *m, const double *c) {
+        double s = m[0] * c[0];
+        s = s + m[1] * c[1];
+        s = s + m[2] * c[2];
+        return s;
+    };
+    k00 = dot3(Mx, Bx_b) * area * thick;
+    k01 = dot3(Mx, By_b) * area * thick;
+    k10 = dot3(My, Bx_b) * area * thick;
+    k11 = dot3(My, By_b) * area * thick;
+}
+
+__global__ void __launch_bounds__(256) k_assemble_rows(const int32_t *brow, const int32_t *bcol, const int32_t *bptr,
+                                                       int64_t nb, const int32_t *inc_off, const uint32_t *inc,
+                                                       const int32_t *iperm, const int32_t *conn, const double2 *xy,
+                                                       double nu, double youngs, double thick, double *kval)
+{
+    const int64_t blk = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (blk >= nb) return;
+    const int32_t i = brow[blk], j = bcol[blk];
+    double D[9];
+    stress_strain(nu, youngs, D);
+    const int32_t g = iperm[i]; // incidence lists are keyed by the Hilbert id
+    double k00 = 0.0, k01 = 0.0, k10 = 0.0, k11 = 0.0;
+    for (int32_t q = inc_off[g]; q < inc_off[g + 1]; ++q) {
+        const uint32_t v = inc[q];
+        const uint32_t e = v / 3u;
+        const int a = (int)(v - 3u * e);
+        const int32_t n0 = conn[3 * (int64_t)e], n1 = conn[3 * (int64_t)e + 1], n2 = conn[3 * (int64_t)e + 2];
+        if (n0 != j && n1 != j && n2 != j) continue;
+        const double2 v0 = xy[n0], v1 = xy[n1], v2 = xy[n2];
+        const int32_t nn[3] = {n0, n1, n2};
+#pragma unroll
+        for (int b = 0; b < 3; ++b) { // ascending local column, as the loops of solver.rs:304-322
+            if (nn[b] != j) continue;
+            double c00, c01, c10, c11;
+            ke_block(v0, v1, v2, a, b, D, thick, c00, c01, c10, c11);
+            k00 += c00;
+            k01 += c01;
+            k10 += c10;
+            k11 += c11;
+        }
+    }
+    const int32_t p = bptr[i], cnt = bptr[i + 1] - p, kpos = (int32_t)blk - p;
+    double *r0 = kval + 4 * (int64_t)p + 2 * kpos;
+    double *r1 = kval + 4 * (int64_t)p + 2 * cnt + 2 * kpos;
+    r0[0] = k00;
+    r0[1] = k01;
+    r1[0] = k10;
+    r1[1] = k11;
+}
+
+void assemble_rows(const int32_t *brow, const int32_t *bcol, const int32_t *bptr, int64_t nb, const int32_t *inc_off,
+                   const uint32_t *inc, const int32_t *iperm, const int32_t *conn, const double *xy, double nu,
+                   double youngs, double thick, double *kval, hipStream_t s)
+{
+    k_assemble_rows<<<blocks_for(nb, 256), 256, 0, s>>>(brow, bcol, bptr, nb, inc_off, inc, iperm, conn,
+                                                        (const double2 *)xy, nu, youngs, thick, kval);
+}
+
 // solver.rs:365-404 + 427-432 on the CSR rows: known[r,k] = -(K[r,col]*u[col]) summed ascending, + f.
 __device__ inline double rhs_row(const int32_t *bptr, const int32_t *bcol, const double *kval, const uint8_t *u_known,
                                  const double *u_in, const double *f_in, int64_t r)

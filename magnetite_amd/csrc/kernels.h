@@ -52,9 +52,9 @@ void halo_coords(const int32_t *halo_g, const double *xyP, int64_t n, double *ha
 void csr_pairs(const int32_t *conn, int64_t E, uint64_t *keys, uint32_t *vals, hipStream_t s);
 // head[k] = 1 where sorted key k starts a new (row,col) block
 void csr_heads(const uint64_t *keys, int64_t n, int32_t *head, hipStream_t s);
-// for heads: seg_start[blk] = k, bcol[blk] = col node, rowcnt[row node]++   (blk = exclusive scan of head)
+// for heads: seg_start[blk] = k, brow/bcol[blk] = row/col node, rowcnt[row node]++   (blk = exclusive scan of head)
 void csr_segments(const uint64_t *keys, const int32_t *head, const int32_t *blk, int64_t n, int32_t *seg_start,
-                  int32_t *bcol, int32_t *rowcnt, hipStream_t s);
+                  int32_t *brow, int32_t *bcol, int32_t *rowcnt, hipStream_t s);
 // scalar CSR arrays of K from the node-block pattern
 void csr_export(const int32_t *bptr, const int32_t *bcol, int64_t N, int32_t *rowptr, int32_t *col, hipStream_t s);
 // free-DOF numbering flags: isfree[i] = !u_known[i]
@@ -74,6 +74,10 @@ void element_stiffness(const double *xy, const int32_t *conn, int64_t E, double 
 // sorted pairs in ascending element order into the four scalar CSR slots.
 void assemble_gather(const uint64_t *keys, const uint32_t *vals, const int32_t *seg_start, int64_t nb,
                      const int32_t *bptr, const double *ke, double *kval, hipStream_t s);
+// the same assembly without the K_e buffer: per (row,col) block, only the needed 2x2 blocks of the incident elements
+void assemble_rows(const int32_t *brow, const int32_t *bcol, const int32_t *bptr, int64_t nb, const int32_t *inc_off,
+                   const uint32_t *inc, const int32_t *iperm, const int32_t *conn, const double *xy, double nu,
+                   double youngs, double thick, double *kval, hipStream_t s);
 // solver.rs:365-404,427-432: b[row] = sum_{known cols, ascending} -(K*u) + f  (0 on prescribed rows),
 // written in Hilbert order: bP[2*iperm[node]+a]
 void rhs_from_csr(const int32_t *bptr, const int32_t *bcol, const double *kval, const uint8_t *u_known,

@@ -389,7 +389,8 @@ void csr_heads(const uint64_t *keys, int64_t n, int32_t *head, hipStream_t s)
 }
 
 __global__ void __launch_bounds__(256) k_csr_segments(const uint64_t *keys, const int32_t *head, const int32_t *blk,
-                                                      int64_t n, int32_t *seg_start, int32_t *bcol, int32_t *rowcnt)
+                                                      int64_t n, int32_t *seg_start, int32_t *brow, int32_t *bcol,
+                                                      int32_t *rowcnt)
 {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
@@ -397,6 +398,7 @@ __global__ void __launch_bounds__(256) k_csr_segments(const uint64_t *keys, cons
         const int32_t b = blk[k];
         const uint64_t key = keys[k];
         seg_start[b] = (int32_t)k;
+        brow[b] = (int32_t)(key >> 32);
         bcol[b] = (int32_t)(key & 0xffffffffu);
         atomicAdd(&rowcnt[(int32_t)(key >> 32)], 1);
     }
@@ -404,9 +406,9 @@ __global__ void __launch_bounds__(256) k_csr_segments(const uint64_t *keys, cons
 }
 
 void csr_segments(const uint64_t *keys, const int32_t *head, const int32_t *blk, int64_t n, int32_t *seg_start,
-                  int32_t *bcol, int32_t *rowcnt, hipStream_t s)
+                  int32_t *brow, int32_t *bcol, int32_t *rowcnt, hipStream_t s)
 {
-    k_csr_segments<<<blocks_for(n, 256), 256, 0, s>>>(keys, head, blk, n, seg_start, bcol, rowcnt);
+    k_csr_segments<<<blocks_for(n, 256), 256, 0, s>>>(keys, head, blk, n, seg_start, brow, bcol, rowcnt);
 }
 
 // rows 2i and 2i+1 share node i's block pattern: row 2i holds (2j,2j+1) for each j, then row 2i+1 the same.
