@@ -492,6 +492,10 @@ size_t op_lds_bytes(int32_t cap, int32_t B) { return (size_t)cap * 32 + (size_t)
 // plain SpMV launches need no dot partials, so their grid is free: one persistent round (all workgroups co-resident)
 static int op_plain_grid(int32_t B, int32_t cap, int32_t tiles)
 {
+    // the occupancy query is a host API call: do it once per (B, cap), not per launch
+    static thread_local int32_t c_B = 0, c_cap = 0;
+    static thread_local long c_resident = 0;
+    if (c_B == B && c_cap == cap && c_resident > 0) return (int)(c_resident > tiles ? tiles : c_resident);
     int dev = 0, cus = 256, per_cu = 1;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -505,6 +509,9 @@ static int op_plain_grid(int32_t B, int32_t cap, int32_t tiles)
         e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_operator_lds<512, false, false>, 512, lds);
     if (e != hipSuccess || per_cu < 1) per_cu = 1;
     long g = (long)per_cu * cus;
+    c_B = B;
+    c_cap = cap;
+    c_resident = g;
     if (g > tiles) g = tiles;
     return g < 1 ? 1 : (int)g;
 }
