@@ -938,7 +938,6 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
     FusedState *st = P.st;
     const long long j = st->jslot[P.par];
     const int was_done = st->done;
-    if (was_done) return; // launches queued behind the converged one: nothing to load, nothing to reduce
     const double target = st->target;
     const long long max_iter = st->max_iter;
     const int stop_mode = st->stop_mode;
@@ -1113,7 +1112,6 @@ __global__ void __launch_bounds__(B) k_cg_fused_dma(const FusedParams P)
     FusedState *st = P.st;
     const long long j = st->jslot[P.par];
     const int was_done = st->done;
-    if (was_done) return; // launches queued behind the converged one: nothing to load, nothing to reduce
     const double target = st->target;
     const long long max_iter = st->max_iter;
     const int stop_mode = st->stop_mode;
@@ -1515,7 +1513,6 @@ __global__ void __launch_bounds__(B) k_cg_fused32(const Fused32Params P)
     FusedState *st = P.st;
     const long long j = st->jslot[P.par];
     const int was_done = st->done;
-    if (was_done) return; // launches queued behind the converged one: nothing to load, nothing to reduce
     const double target = st->target;
     const long long max_iter = st->max_iter;
     const int stop_mode = st->stop_mode;
