@@ -487,3 +487,26 @@ def test_random_unstructured_meshes(built, seed):
     assert rel(out["u"], ref["u"]) <= TOL_U
     # near the absolute threshold the residual wanders at round-off level: a few per cent of slack on the count
     assert abs(out["iterations"] - ref["iterations"]) <= max(5, ref["iterations"] // 20)
+
+
+def test_empty_and_inconsistent_inputs_are_errors(built):
+    from magnetite_amd._lib import MAG_ERR_STATE
+    p = PROBLEMS["plate12"]
+    with Context(device=0) as c:
+        with pytest.raises(MagnetiteError) as ei:       # nothing uploaded yet
+            c.run()
+        assert ei.value.code == MAG_ERR_STATE
+        with pytest.raises(MagnetiteError) as ei:       # empty mesh
+            c.upload(np.zeros(0), np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.uint8), np.zeros(0), np.zeros(0),
+                     1.0, 0.3, 1.0)
+        assert ei.value.code == MAG_ERR_BAD_ARGS
+        with pytest.raises(MagnetiteError):             # boundary arrays of the wrong length
+            c.upload(p.xy_flat, p.conn_flat, p.u_known[:-2], p.u_in, p.f_in, 1.0, 0.3, 1.0)
+        with pytest.raises(MagnetiteError) as ei:       # nu = 1 makes D singular (division by 1 - nu^2)
+            c.upload(p.xy_flat, p.conn_flat, p.u_known, p.u_in, p.f_in, 1.0, 1.0, 1.0)
+        assert ei.value.code == MAG_ERR_BAD_ARGS
+        c.upload_problem(p)                             # the context is still usable afterwards
+        c.run()
+        with pytest.raises(MagnetiteError):             # history was not requested
+            c.history(4)
+        assert c.stats()["converged"] == 1
