@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--workload", default="hole1m")
     ap.add_argument("--tol", type=float, default=1e-8)
     ap.add_argument("--stop", default="rel", choices=["rel", "rnorm", "rnorm_sq"])
-    ap.add_argument("--tile", type=int, default=512)
+    ap.add_argument("--tile", type=int, default=0, help="0: library default (512 for >= 262144 nodes, else 256)")
     ap.add_argument("--check-every", type=int, default=64)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cg-variant", type=int, default=1, help="1: one fused launch per CG iteration, 0: two launches")
@@ -152,6 +152,8 @@ def main():
         elapsed = float(t.item())
 
     st = ctx.stats()
+    if args.tile == 0:
+        args.tile = 512 if N >= 512 * 512 else 256  # what the library chose (mag_options.tile_nodes = 0)
     # HIP events on the library's own stream around op_reps back-to-back launches (mag_time_operator / mag_time_spmv)
     ms_op = ctx.time_operator(args.op_reps)   # the CG iteration kernel (dominant: one launch per iteration)
     ms_spmv = ctx.time_spmv(args.op_reps)     # the plain matrix-free SpMV y = M K M v

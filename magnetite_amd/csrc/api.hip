@@ -197,6 +197,10 @@ int ensure_order(mag_ctx *ctx)
 {
     if (ctx->have_order) return MAG_OK;
     const int64_t N = ctx->N, E = ctx->E;
+    // automatic tile size: 512-node tiles once the mesh has at least as many of them as the fused kernel keeps
+    // resident (2 per CU x 256 CUs); smaller meshes are latency-bound and run faster on twice as many 256-node tiles
+    // (measured: 100k triangles 6.6 vs 7.7 us per iteration; 1M triangles 22.0 vs 20.4)
+    if (ctx->opt.tile_nodes == 0) ctx->B = (N >= 512 * 512) ? 512 : 256;
     const int32_t B = ctx->B;
     const int32_t T = (int32_t)((N + B - 1) / B);
     ctx->T = T;
@@ -1056,7 +1060,7 @@ void mag_default_options(mag_options *o)
     o->assemble_csr = 1;
     o->check_every = 64;
     o->use_graph = 1;
-    o->tile_nodes = 512;
+    o->tile_nodes = 0;
     o->history_len = 0;
     o->verbose = 0;
     o->op_variant = 0;
@@ -1073,14 +1077,14 @@ mag_ctx *mag_create(const mag_options *opt)
     else
         mag_default_options(&ctx->opt);
     mag_options &o = ctx->opt;
-    if (o.tile_nodes != 256 && o.tile_nodes != 512 && o.tile_nodes != 1024) o.tile_nodes = 512;
+    if (o.tile_nodes != 256 && o.tile_nodes != 512 && o.tile_nodes != 1024) o.tile_nodes = 0; // 0 = automatic
     if (o.check_every < 2) o.check_every = 2;
     if (o.check_every & 1) ++o.check_every; // p ping-pong parity must restart at 0 every block
     if (o.check_every > 4096) o.check_every = 4096;
     if (o.max_iter < 0) o.max_iter = 0;
     if (o.history_len < 0) o.history_len = 0;
     if (!(o.tol >= 0.0)) o.tol = MAG_TARGET_CG_COST;
-    ctx->B = o.tile_nodes;
+    ctx->B = o.tile_nodes ? o.tile_nodes : 512;
     ctx->device = o.device;
     if (const char *e = getenv("MAG_TUNE_WT")) ctx->tune_wt = ctx->tune_wt_fused = atoi(e);
     hipError_t e = hipSetDevice(ctx->device);

@@ -61,7 +61,7 @@ def test_version_defaults_and_constants(built):
     L.mag_default_options(C.byref(o))
     # solver.rs:17-19
     assert o.tol == 1e-4 and o.max_iter == int(1e7) and o.stop_mode == _lib.MAG_STOP_RNORM
-    assert o.cg_operator == _lib.MAG_OP_MATRIX_FREE and o.assemble_csr == 1 and o.tile_nodes == 512
+    assert o.cg_operator == _lib.MAG_OP_MATRIX_FREE and o.assemble_csr == 1 and o.tile_nodes == 0
     hdr = open(HEADER).read()
     assert "#define MAG_DOF 2" in hdr and "#define MAG_MAX_CG_ITER 10000000LL" in hdr
     assert "#define MAG_TARGET_CG_COST 1e-4" in hdr
