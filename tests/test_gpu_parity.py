@@ -510,3 +510,24 @@ def test_empty_and_inconsistent_inputs_are_errors(built):
         with pytest.raises(MagnetiteError):             # history was not requested
             c.history(4)
         assert c.stats()["converged"] == 1
+
+
+def test_fused_beta_expansion_tracks_the_exact_recurrence(built):
+    """cg_variant 1 expands |r_new|^2 = r.r + 2 alpha r.q + alpha^2 q.q instead of reducing it a second time; over
+    hundreds of iterations its cost history must stay on top of the two-launch variant's (same argmin recurrences
+    with every dot product reduced directly) and of the oracle's."""
+    p = meshgen.config_fixed_left_pull_right(meshgen.shuffle(meshgen.plate_with_holes(96), 4))
+    n = 400
+    hist = {}
+    for variant in (0, 1):
+        with Context(device=0, cg_variant=variant, history_len=n, max_iter=n) as c:
+            out = c.solve(p, allow_not_converged=True)
+            assert out["iterations"] == n
+            hist[variant] = c.history(n)
+    K = oracle.assemble_sparse(p.xy_flat, p.conn_flat, p.poisson_ratio, p.youngs_modulus, p.part_thickness)
+    A, b = oracle.reduce_system(K, p.u_known, p.u_in, p.f_in)
+    _, _, _, href = oracle.cg(A, b, max_iter=n, hist_len=n)
+    # CG amplifies rounding differences slowly: tight early, still close after 400 iterations
+    assert np.allclose(hist[1][:50], hist[0][:50], rtol=1e-10)
+    assert np.allclose(hist[1], hist[0], rtol=1e-6)
+    assert np.allclose(hist[1][:50], href[:50], rtol=1e-10) and np.allclose(hist[1], href, rtol=1e-6)
