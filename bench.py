@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--op-reps", type=int, default=400)
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="world size 1 only: still create the nccl process group and the RCCL communicator and run "
-                         "the distributed CG protocol (pack / all-reduce / unpack every iteration)")
+                         "the distributed CG protocol (iteration kernel + one in-place all-reduce every iteration)")
     args = ap.parse_args()
 
     import torch  # first: libmagnetite_hip.so then shares torch's HIP runtime and RCCL (same SONAMEs)

@@ -100,10 +100,12 @@ struct mag_ctx {
     // CG (Hilbert numbering)
     DevBuf x, r, p0, p1, q, bP, tmpP, partRR, partPQ, state, hist;
     // fused single-launch variant
-    DevBuf rqp0, rqp1, fpart, fstate, tmeta, comm_f;
+    DevBuf rqp0, rqp1, fpart, fstate, tmeta, comm_f, own_qslot, halo_qslot;
     magk::FusedState *h_fstate = nullptr; // pinned, 3 slots
     bool fused = false;
     int32_t fgrid = 1; // workgroups of the fused kernel for this problem
+    int32_t g_all = 1; // ... of the rank with the most tiles: dot-partial slots of the exchange buffer (multi-GPU)
+    size_t cwords = 0; // doubles per exchange buffer: 4 * g_all + 2 * n_iface
     DevBuf xy32, hxy32, rqp32a, rqp32b, x32; // fp32 leg (mag_options.precision = 1)
     hipGraphExec_t graph = nullptr;
     struct GraphKey {
@@ -702,14 +704,23 @@ magk::FusedParams fused_params(mag_ctx *ctx, int par)
     P.in = (par ? ctx->rqp1 : ctx->rqp0).as<magk::Rqp>();
     P.out = (par ? ctx->rqp0 : ctx->rqp1).as<magk::Rqp>();
     P.x = ctx->x.as<double2>();
-    double *part = ctx->fpart.as<double>();
-    P.part_out = part + (size_t)(par ^ 1) * 4 * stride;
-    P.part_stride = stride;
     if (ctx->dist) {
-        P.part_in = ctx->comm_f.as<double>();
-        P.part_stride_in = 1;
-        P.nPart = 1;
+        // exchange buffers, one per parity: launch `par` reads the all-reduced buffer [par], fills buffer [par ^ 1]
+        double *cin = ctx->comm_f.as<double>() + (size_t)par * ctx->cwords;
+        double *cout = ctx->comm_f.as<double>() + (size_t)(par ^ 1) * ctx->cwords;
+        P.part_in = cin;
+        P.part_stride_in = ctx->g_all;
+        P.nPart = ctx->g_all;
+        P.part_out = cout;
+        P.part_stride = ctx->g_all;
+        P.comm_in_q = (const double2 *)(cin + 4 * (size_t)ctx->g_all);
+        P.comm_out_q = (double2 *)(cout + 4 * (size_t)ctx->g_all);
+        P.own_qslot = ctx->own_qslot.as<int32_t>();
+        P.halo_qslot = ctx->halo_qslot.as<int32_t>();
     } else {
+        double *part = ctx->fpart.as<double>();
+        P.part_out = part + (size_t)(par ^ 1) * 4 * stride;
+        P.part_stride = stride;
         P.part_in = part + (size_t)par * 4 * stride;
         P.part_stride_in = stride;
         P.nPart = ctx->fgrid;
@@ -721,19 +732,15 @@ magk::FusedParams fused_params(mag_ctx *ctx, int par)
 
 int fused_block(mag_ctx *ctx, int G)
 {
-    const int nloc = ctx->fgrid;
     for (int i = 0; i < G; ++i) {
         const magk::FusedParams P = fused_params(ctx, i & 1);
         magk::fused_launch(P, ctx->B, ctx->fgrid, ctx->stream);
         if (ctx->dist) {
-            // the iteration's ONE collective: [r.r, p.q, r.q, q.q partial sums | q on owned interface nodes]
-            magk::fused_pack(P.part_out, nloc, P.part_stride, P.out, ctx->iface.as<int32_t>(), ctx->n_iface, ctx->own0,
-                             ctx->own1, ctx->comm_f.as<double>(), ctx->stream);
+            // the iteration's ONE collective, in place on the buffer the launch just filled:
+            // [r.r, p.q, r.q, q.q partials, slot by slot | q on interface nodes (owner's value + zeros)]
             std::string msg;
-            if (int rc = ctx->comm.allreduce_sum(ctx->comm_f.as<double>(), 4 + 2 * (int64_t)ctx->n_iface, ctx->stream, msg))
+            if (int rc = ctx->comm.allreduce_sum(P.part_out, (int64_t)ctx->cwords, ctx->stream, msg))
                 return fail(ctx, rc, "%s", msg.c_str());
-            magk::fused_unpack(ctx->comm_f.as<double>(), ctx->iface.as<int32_t>(), ctx->n_iface, ctx->own0, ctx->own1,
-                               P.out, ctx->stream);
         }
     }
     HIPCHK(hipGetLastError());
@@ -746,7 +753,24 @@ int reserve_fused(mag_ctx *ctx)
     HIPCHK(ctx->rqp1.reserve(sizeof(magk::Rqp) * (size_t)ctx->N));
     HIPCHK(ctx->fpart.reserve(8 * 2 * 4 * (size_t)magk::kMaxGrid));
     HIPCHK(ctx->fstate.reserve(sizeof(magk::FusedState)));
-    HIPCHK(ctx->comm_f.reserve(8 * (4 + 2 * (size_t)ctx->n_iface) + 64));
+    ctx->fgrid = magk::fused_grid(ctx->B, ctx->cap, ctx->t1 - ctx->t0, ctx->dist);
+    if (ctx->dist) {
+        // every rank computes the same g_all: same device, same cap, tile counts from the same arithmetic
+        const int R = ctx->comm.nranks;
+        int32_t most = 1;
+        for (int r = 0; r < R; ++r) {
+            const int32_t n = (int32_t)(((int64_t)ctx->T * (r + 1)) / R - ((int64_t)ctx->T * r) / R);
+            most = std::max(most, n);
+        }
+        ctx->g_all = magk::fused_grid(ctx->B, ctx->cap, most, true);
+        ctx->cwords = 4 * (size_t)ctx->g_all + 2 * (size_t)ctx->n_iface;
+        HIPCHK(ctx->comm_f.reserve(8 * 2 * ctx->cwords + 64));
+        HIPCHK(ctx->own_qslot.reserve(4 * (size_t)ctx->N));
+        HIPCHK(ctx->halo_qslot.reserve(4 * (size_t)std::max<int64_t>(ctx->halo_total, 1)));
+        magk::comm_slots(ctx->iface.as<int32_t>(), ctx->n_iface, ctx->own0, ctx->own1, ctx->halo_g.as<int32_t>(),
+                         ctx->halo_total, ctx->N, ctx->own_qslot.as<int32_t>(), ctx->halo_qslot.as<int32_t>(),
+                         ctx->stream);
+    }
     return MAG_OK;
 }
 
@@ -792,19 +816,21 @@ int cg_phase_fused(mag_ctx *ctx)
     hipStream_t s = ctx->stream;
     if (int rc = reserve_fused(ctx)) return rc;
     const int32_t stride = magk::kMaxGrid;
-    ctx->fgrid = magk::fused_grid(ctx->B, ctx->cap, ctx->t1 - ctx->t0);
     HIPCHK(hipMemsetAsync(ctx->x.p, 0, 16 * (size_t)ctx->N, s));
-    HIPCHK(hipMemsetAsync(ctx->fpart.p, 0, 8 * 2 * 4 * (size_t)stride, s));
-    magk::fused_init(ctx->bP.as<double2>(), ctx->rqp0.as<magk::Rqp>(), ctx->rqp1.as<magk::Rqp>(), ctx->N, ctx->B,
-                     ctx->T, ctx->t0, ctx->t1, ctx->fpart.as<double>(), stride, ctx->fgrid, s);
     if (ctx->dist) {
-        magk::fused_pack(ctx->fpart.as<double>(), ctx->fgrid, stride, nullptr, nullptr, 0, 0, 0,
-                         ctx->comm_f.as<double>(), s);
+        // b.b partials go straight into exchange buffer 0 (its q part = q_{-1} = 0), summed over ranks in place
+        double *c0 = ctx->comm_f.as<double>();
+        HIPCHK(hipMemsetAsync(c0, 0, 8 * 2 * ctx->cwords, s));
+        magk::fused_init(ctx->bP.as<double2>(), ctx->rqp0.as<magk::Rqp>(), ctx->rqp1.as<magk::Rqp>(), ctx->N, ctx->B,
+                         ctx->T, ctx->t0, ctx->t1, c0, ctx->g_all, ctx->fgrid, s);
         std::string msg;
-        if (int rc = ctx->comm.allreduce_sum(ctx->comm_f.as<double>(), 4, s, msg)) return fail(ctx, rc, "%s", msg.c_str());
-        magk::fused_setup(ctx->comm_f.as<double>(), 1, 1, ctx->opt.stop_mode, ctx->opt.tol, (long long)ctx->opt.max_iter,
+        if (int rc = ctx->comm.allreduce_sum(c0, (int64_t)ctx->cwords, s, msg)) return fail(ctx, rc, "%s", msg.c_str());
+        magk::fused_setup(c0, ctx->g_all, ctx->g_all, ctx->opt.stop_mode, ctx->opt.tol, (long long)ctx->opt.max_iter,
                           ctx->fstate.as<FusedState>(), s);
     } else {
+        HIPCHK(hipMemsetAsync(ctx->fpart.p, 0, 8 * 2 * 4 * (size_t)stride, s));
+        magk::fused_init(ctx->bP.as<double2>(), ctx->rqp0.as<magk::Rqp>(), ctx->rqp1.as<magk::Rqp>(), ctx->N, ctx->B,
+                         ctx->T, ctx->t0, ctx->t1, ctx->fpart.as<double>(), stride, ctx->fgrid, s);
         magk::fused_setup(ctx->fpart.as<double>(), ctx->fgrid, stride, ctx->opt.stop_mode, ctx->opt.tol,
                           (long long)ctx->opt.max_iter, ctx->fstate.as<FusedState>(), s);
     }
@@ -1122,7 +1148,7 @@ void mag_destroy(mag_ctx *ctx)
                           &ctx->val_ff, &ctx->b_ff, &ctx->rp_full, &ctx->col_full, &ctx->x, &ctx->r, &ctx->p0,
                           &ctx->p1, &ctx->q, &ctx->bP, &ctx->tmpP, &ctx->partRR, &ctx->partPQ, &ctx->state,
                           &ctx->hist, &ctx->u, &ctx->f, &ctx->stress, &ctx->rqp0, &ctx->rqp1, &ctx->fpart, &ctx->fstate,
-                          &ctx->tmeta, &ctx->comm_f, &ctx->xy32, &ctx->hxy32, &ctx->rqp32a, &ctx->rqp32b, &ctx->x32};
+                          &ctx->tmeta, &ctx->comm_f, &ctx->own_qslot, &ctx->halo_qslot, &ctx->xy32, &ctx->hxy32, &ctx->rqp32a, &ctx->rqp32b, &ctx->x32};
         for (DevBuf *b : bufs) b->release();
         if (ctx->h_state) (void)hipHostFree(ctx->h_state);
         if (ctx->h_fstate) (void)hipHostFree(ctx->h_fstate);
@@ -1452,6 +1478,9 @@ int mag_time_operator(mag_ctx *ctx, int32_t reps, double *ms_per_launch)
         P.part_stride_in = stride;
         P.nPart = 1;
         P.n_iface = 0;
+        P.own_qslot = P.halo_qslot = nullptr; // single-GPU kernel: the figure is the operator's, not the exchange's
+        P.comm_in_q = nullptr;
+        P.comm_out_q = nullptr;
         for (int i = 0; i < 3; ++i) magk::fused_launch(P, ctx->B, ctx->fgrid, s);
         HIPCHK(hipEventRecord(ctx->ev[8], s));
         for (int i = 0; i < reps; ++i) magk::fused_launch(P, ctx->B, ctx->fgrid, s);

@@ -925,7 +925,11 @@ __device__ inline void block_sum4(double (&v)[4], double *s_red)
     }
 }
 
-template <int B, bool WT>
+// COMM (multi-GPU): the launch reads the all-reduced exchange buffer of the previous iteration directly (dot partials
+// summed over ranks slot by slot, q of interface nodes other ranks own) and writes its own contribution to the next
+// one (partials, q of the interface nodes it owns, zeros elsewhere), so a distributed iteration is this kernel plus
+// ONE in-place all-reduce -- no pack/unpack launches.
+template <int B, bool WT, bool COMM>
 __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
 {
     extern __shared__ __attribute__((aligned(16))) double2 smem[];
@@ -946,7 +950,7 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
     bool valid = false, hvalid = false;
     double2 ca, ar, aq, ap, xo, hc, hr, hq, hp;
     uint8_t m = 3;
-    int32_t deg = 0, nh = 0, hoff = 0, hg = 0;
+    int32_t deg = 0, nh = 0, hoff = 0, hg = 0, oslot = -1;
     uint32_t w[kSlotRegs];
     const uint32_t *ell = nullptr;
     auto load_tile = [&](int32_t t) {
@@ -955,6 +959,7 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
         valid = node < P.N;
         ca = ar = aq = ap = xo = make_double2(0.0, 0.0);
         m = 3;
+        oslot = -1;
         if (valid) {
             const Rqp rec = P.in[node];
             ar = rec.r;
@@ -963,6 +968,7 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
             xo = P.x[node];
             ca = P.xyP[node];
             m = P.maskP[node];
+            if (COMM) oslot = P.own_qslot[node];
         }
         deg = tm.deg;
         ell = P.ell16 + tm.ell_off + tid;
@@ -979,6 +985,10 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
             hr = rec.r;
             hq = rec.q;
             hp = rec.p;
+            if (COMM) {
+                const int32_t hs = P.halo_qslot[hoff + tid];
+                if (hs >= 0) hq = P.comm_in_q[hs];
+            }
         }
     };
     load_tile(P.t0 + blockIdx.x);
@@ -1021,9 +1031,14 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
         for (int32_t hh = tid + B; hh < nh; hh += B) { // more halo nodes than threads (rare)
             const int32_t g = P.halo_g[hoff + hh];
             const Rqp rec = P.in[g];
+            double2 hq2 = rec.q;
+            if (COMM) {
+                const int32_t hs = P.halo_qslot[hoff + hh];
+                if (hs >= 0) hq2 = P.comm_in_q[hs];
+            }
             double2 hrn, hpn;
-            hrn.x = rec.r.x + alpha * rec.q.x;
-            hrn.y = rec.r.y + alpha * rec.q.y;
+            hrn.x = rec.r.x + alpha * hq2.x;
+            hrn.y = rec.r.y + alpha * hq2.y;
             hpn.x = -hrn.x + beta * rec.p.x;
             hpn.y = -hrn.y + beta * rec.p.y;
             s_xy[B + hh] = P.halo_xy[hoff + hh];
@@ -1055,6 +1070,7 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
             store2<WT>((double2 *)P.out, 3 * P.N, 3 * node + 1, make_double2(fx, fy));
             store2<WT>((double2 *)P.out, 3 * P.N, 3 * node + 2, pn);
             store2<WT>(P.x, P.N, node, xo);
+            if (COMM && oslot >= 0) P.comm_out_q[oslot] = make_double2(fx, fy);
             acc[0] += rn.x * rn.x + rn.y * rn.y;
             acc[1] += pn.x * fx + pn.y * fy;
             acc[2] += rn.x * fx + rn.y * fy;
@@ -1064,18 +1080,30 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
         if (t >= P.t1) break;
         load_tile(t);
     }
-    // multi-GPU: records of interface nodes other ranks own are advanced locally (their q arrives by all-reduce)
-    for (int32_t k = blockIdx.x * B + tid; k < P.n_iface; k += gridDim.x * B) {
-        const int32_t g = P.iface[k];
-        if (g < P.own0 || g >= P.own1) {
-            const Rqp rec = P.in[g];
-            double2 rn, pn;
-            rn.x = rec.r.x + alpha * rec.q.x;
-            rn.y = rec.r.y + alpha * rec.q.y;
-            pn.x = -rn.x + beta * rec.p.x;
-            pn.y = -rn.y + beta * rec.p.y;
-            P.out[g].r = rn;
-            P.out[g].p = pn;
+    if (COMM) {
+        // records of interface nodes other ranks own are advanced locally: q_{j-1} from the exchange buffer, r and p by
+        // the same recurrences their owner runs; their slot of the outgoing buffer is this rank's zero
+        for (int32_t k = blockIdx.x * B + tid; k < P.n_iface; k += gridDim.x * B) {
+            const int32_t g = P.iface[k];
+            if (g < P.own0 || g >= P.own1) {
+                const Rqp rec = P.in[g];
+                const double2 qg = P.comm_in_q[k];
+                double2 rn, pn;
+                rn.x = rec.r.x + alpha * qg.x;
+                rn.y = rec.r.y + alpha * qg.y;
+                pn.x = -rn.x + beta * rec.p.x;
+                pn.y = -rn.y + beta * rec.p.y;
+                P.out[g].r = rn;
+                P.out[g].p = pn;
+                P.comm_out_q[k] = make_double2(0.0, 0.0);
+            }
+        }
+        // partial slots other ranks fill but this (smaller) grid does not
+        if (blockIdx.x == 0) {
+            for (int32_t i = gridDim.x + tid; i < P.part_stride; i += B) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) P.part_out[c * P.part_stride + i] = 0.0;
+            }
         }
     }
     block_sum4<B>(acc, s_red);
@@ -1085,7 +1113,7 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
     }
 }
 
-template <int B, bool WT>
+template <int B, bool WT, bool COMM>
 __global__ void __launch_bounds__(B) k_cg_fused_dma(const FusedParams P)
 {
     extern __shared__ __attribute__((aligned(16))) double2 smem[];
@@ -1120,7 +1148,7 @@ __global__ void __launch_bounds__(B) k_cg_fused_dma(const FusedParams P)
     bool valid = false, hvalid = false;
     double2 xo;
     uint8_t m = 3;
-    int32_t deg = 0, nh = 0, hoff = 0;
+    int32_t deg = 0, nh = 0, hoff = 0, oslot = -1;
     uint32_t w[kSlotRegs];
     const uint32_t *ell = nullptr;
     // callers guarantee that no wave still reads s_xy / the stages of the previous tile (barrier before the call)
@@ -1143,9 +1171,11 @@ __global__ void __launch_bounds__(B) k_cg_fused_dma(const FusedParams P)
             __builtin_amdgcn_global_load_lds((glb_void *)(P.xyP + node), (lds_void *)(s_xy + wv * 64), 16, 0, 0);
         xo = make_double2(0.0, 0.0);
         m = 3;
+        oslot = -1;
         if (valid) {
             xo = P.x[node];
             m = P.maskP[node];
+            if (COMM) oslot = P.own_qslot[node];
         }
         deg = tm.deg;
         ell = P.ell16 + tm.ell_off + tid;
@@ -1154,8 +1184,13 @@ __global__ void __launch_bounds__(B) k_cg_fused_dma(const FusedParams P)
         if (hvalid) {
             __builtin_amdgcn_global_load_lds((glb_void *)(P.halo_xy + hoff + tid), (lds_void *)(s_xy + B + wv * 64), 16, 0, 0);
             const double2 *src = (const double2 *)(P.in + hg);
+            const double2 *qsrc = src + 1;
+            if (COMM) {
+                const int32_t hs = P.halo_qslot[hoff + tid];
+                if (hs >= 0) qsrc = P.comm_in_q + hs;
+            }
             __builtin_amdgcn_global_load_lds((glb_void *)(src), (lds_void *)(s_hr + wv * 64), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void *)(src + 1), (lds_void *)(s_hq + wv * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void *)(qsrc), (lds_void *)(s_hq + wv * 64), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((glb_void *)(src + 2), (lds_void *)(s_hp + wv * 64), 16, 0, 0);
         }
     };
@@ -1202,9 +1237,14 @@ __global__ void __launch_bounds__(B) k_cg_fused_dma(const FusedParams P)
         for (int32_t hh = tid + B; hh < nh; hh += B) { // more halo nodes than threads (rare)
             const int32_t g = P.halo_g[hoff + hh];
             const Rqp rec = P.in[g];
+            double2 hq2 = rec.q;
+            if (COMM) {
+                const int32_t hs = P.halo_qslot[hoff + hh];
+                if (hs >= 0) hq2 = P.comm_in_q[hs];
+            }
             double2 hrn, hpn;
-            hrn.x = rec.r.x + alpha * rec.q.x;
-            hrn.y = rec.r.y + alpha * rec.q.y;
+            hrn.x = rec.r.x + alpha * hq2.x;
+            hrn.y = rec.r.y + alpha * hq2.y;
             hpn.x = -hrn.x + beta * rec.p.x;
             hpn.y = -hrn.y + beta * rec.p.y;
             s_xy[B + hh] = P.halo_xy[hoff + hh];
@@ -1243,6 +1283,7 @@ __global__ void __launch_bounds__(B) k_cg_fused_dma(const FusedParams P)
         }
         if (valid) {
             store2<WT>(P.x, P.N, node, xo);
+            if (COMM && oslot >= 0) P.comm_out_q[oslot] = make_double2(fx, fy);
             acc[0] += rn.x * rn.x + rn.y * rn.y;
             acc[1] += pn.x * fx + pn.y * fy;
             acc[2] += rn.x * fx + rn.y * fy;
@@ -1253,18 +1294,30 @@ __global__ void __launch_bounds__(B) k_cg_fused_dma(const FusedParams P)
         __syncthreads(); // every wave is done with this tile's LDS images before the next tile's DMA overwrites them
         load_tile(t);
     }
-    // multi-GPU: records of interface nodes other ranks own are advanced locally (their q arrives by all-reduce)
-    for (int32_t k = blockIdx.x * B + tid; k < P.n_iface; k += gridDim.x * B) {
-        const int32_t g = P.iface[k];
-        if (g < P.own0 || g >= P.own1) {
-            const Rqp rec = P.in[g];
-            double2 rn, pn;
-            rn.x = rec.r.x + alpha * rec.q.x;
-            rn.y = rec.r.y + alpha * rec.q.y;
-            pn.x = -rn.x + beta * rec.p.x;
-            pn.y = -rn.y + beta * rec.p.y;
-            P.out[g].r = rn;
-            P.out[g].p = pn;
+    if (COMM) {
+        // records of interface nodes other ranks own are advanced locally: q_{j-1} from the exchange buffer, r and p by
+        // the same recurrences their owner runs; their slot of the outgoing buffer is this rank's zero
+        for (int32_t k = blockIdx.x * B + tid; k < P.n_iface; k += gridDim.x * B) {
+            const int32_t g = P.iface[k];
+            if (g < P.own0 || g >= P.own1) {
+                const Rqp rec = P.in[g];
+                const double2 qg = P.comm_in_q[k];
+                double2 rn, pn;
+                rn.x = rec.r.x + alpha * qg.x;
+                rn.y = rec.r.y + alpha * qg.y;
+                pn.x = -rn.x + beta * rec.p.x;
+                pn.y = -rn.y + beta * rec.p.y;
+                P.out[g].r = rn;
+                P.out[g].p = pn;
+                P.comm_out_q[k] = make_double2(0.0, 0.0);
+            }
+        }
+        // partial slots other ranks fill but this (smaller) grid does not
+        if (blockIdx.x == 0) {
+            for (int32_t i = gridDim.x + tid; i < P.part_stride; i += B) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) P.part_out[c * P.part_stride + i] = 0.0;
+            }
         }
     }
     block_sum4<B>(acc, s_red);
@@ -1285,25 +1338,29 @@ static bool fused_dma()
     return v != 0;
 }
 
-int fused_grid(int32_t B, int32_t cap, int32_t tiles)
+int fused_grid(int32_t B, int32_t cap, int32_t tiles, bool comm)
 {
     int dev = 0, cus = 256, per_cu = 1;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const bool dma = fused_dma();
+    const bool dma = fused_dma() && B != 1024;
     const size_t lds = fused_lds_bytes(cap, B, dma);
     hipError_t e;
+#define MAG_OCC(K, BB)                                                                                                 \
+    e = comm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, K<BB, false, true>, BB, lds)                      \
+             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, K<BB, false, false>, BB, lds)
     if (dma) {
         if (B == 256)
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_fused_dma<256, false>, 256, lds);
+            MAG_OCC(k_cg_fused_dma, 256);
         else
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_fused_dma<512, false>, 512, lds);
+            MAG_OCC(k_cg_fused_dma, 512);
     } else if (B == 256)
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_fused<256, false>, 256, lds);
+        MAG_OCC(k_cg_fused, 256);
     else if (B == 1024)
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_fused<1024, false>, 1024, lds);
+        MAG_OCC(k_cg_fused, 1024);
     else
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_fused<512, false>, 512, lds);
+        MAG_OCC(k_cg_fused, 512);
+#undef MAG_OCC
     if (e != hipSuccess || per_cu < 1) per_cu = 1;
     long g = (long)per_cu * cus;
     if (g > kMaxGrid) g = kMaxGrid;
@@ -1314,27 +1371,33 @@ int fused_grid(int32_t B, int32_t cap, int32_t tiles)
 void fused_launch(const FusedParams &P, int32_t B, int32_t grid, hipStream_t s)
 {
     const bool dma = fused_dma() && B != 1024;
+    const bool comm = P.comm_out_q != nullptr;
     const size_t lds = fused_lds_bytes(P.cap, B, dma);
+#define MAG_FUSED(K, BB, WTV)                                                                                          \
+    do {                                                                                                               \
+        if (comm)                                                                                                      \
+            K<BB, WTV, true><<<grid, BB, lds, s>>>(P);                                                                 \
+        else                                                                                                           \
+            K<BB, WTV, false><<<grid, BB, lds, s>>>(P);                                                                \
+    } while (0)
     if (dma) {
         if (B == 256 && P.wt)
-            k_cg_fused_dma<256, true><<<grid, 256, lds, s>>>(P);
+            MAG_FUSED(k_cg_fused_dma, 256, true);
         else if (B == 256)
-            k_cg_fused_dma<256, false><<<grid, 256, lds, s>>>(P);
+            MAG_FUSED(k_cg_fused_dma, 256, false);
         else if (P.wt)
-            k_cg_fused_dma<512, true><<<grid, 512, lds, s>>>(P);
+            MAG_FUSED(k_cg_fused_dma, 512, true);
         else
-            k_cg_fused_dma<512, false><<<grid, 512, lds, s>>>(P);
+            MAG_FUSED(k_cg_fused_dma, 512, false);
         return;
     }
     // per-lane 48-byte-stride records: 16-byte write-through pieces measured slower than plain stores here
-#define MAG_FUSED(BB) k_cg_fused<BB, false><<<grid, BB, lds, s>>>(P);
-    if (B == 256) {
-        MAG_FUSED(256)
-    } else if (B == 1024) {
-        MAG_FUSED(1024)
-    } else {
-        MAG_FUSED(512)
-    }
+    if (B == 256)
+        MAG_FUSED(k_cg_fused, 256, false);
+    else if (B == 1024)
+        MAG_FUSED(k_cg_fused, 1024, false);
+    else
+        MAG_FUSED(k_cg_fused, 512, false);
 #undef MAG_FUSED
 }
 
@@ -1382,7 +1445,7 @@ __global__ void __launch_bounds__(B) k_fused_init(const double2 *bP, Rqp *in, Rq
     const double tot = block_sum<B>(acc, s_red);
     if (threadIdx.x == 0) {
         part[blockIdx.x] = tot;
-        part[stride + blockIdx.x] = blockIdx.x == 0 ? 1.0 : 0.0; // "p.q" = 1: alpha finite, multiplies q = 0
+        part[stride + blockIdx.x] = blockIdx.x == 0 ? 1.0 : 0.0; // "p.q" > 0: alpha finite, multiplies q = 0
         part[2 * stride + blockIdx.x] = 0.0;
         part[3 * stride + blockIdx.x] = 0.0;
     }
@@ -1428,56 +1491,47 @@ void fused_setup(const double *part, int32_t nPart, int32_t stride, int stop_mod
     k_fused_setup<<<1, 256, 0, s>>>(part, nPart, stride, stop_mode, tol, max_iter, st);
 }
 
-__global__ void __launch_bounds__(256) k_fused_pack(const double *part, int nPart, int32_t stride, const Rqp *v,
-                                                    const int32_t *iface, int32_t n_iface, int32_t own0,
-                                                    int32_t own1, double *buf)
+// exchange-buffer slots of the COMM iteration.  own_qslot[node] = k if this rank owns interface node iface[k];
+// halo_qslot[i] = k if halo entry i is interface node iface[k] owned by another rank (its q comes from the buffer);
+// -1 otherwise.  iface is sorted ascending.
+__global__ void __launch_bounds__(256) k_own_qslot(const int32_t *iface, int32_t n_iface, int32_t own0, int32_t own1,
+                                                   int32_t *own_qslot)
 {
-    __shared__ double s_red[16];
-    if (blockIdx.x == 0) {
-        double S[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int i = threadIdx.x; i < nPart; i += 256) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) S[c] += part[c * stride + i];
+    const int32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_iface) return;
+    const int32_t g = iface[k];
+    if (g >= own0 && g < own1) own_qslot[g] = k;
+}
+
+__global__ void __launch_bounds__(256) k_halo_qslot(const int32_t *halo_g, int64_t halo_total, const int32_t *iface,
+                                                    int32_t n_iface, int32_t own0, int32_t own1, int32_t *halo_qslot)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= halo_total) return;
+    const int32_t g = halo_g[i];
+    int32_t slot = -1;
+    if (g < own0 || g >= own1) {
+        int32_t lo = 0, hi = n_iface;
+        while (lo < hi) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (iface[mid] < g)
+                lo = mid + 1;
+            else
+                hi = mid;
         }
-        block_sum4<256>(S, s_red);
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) buf[c] = S[c];
-        }
+        if (lo < n_iface && iface[lo] == g) slot = lo;
     }
-    for (int32_t k = blockIdx.x * 256 + threadIdx.x; k < n_iface; k += gridDim.x * 256) {
-        const int32_t g = iface[k];
-        const bool mine = g >= own0 && g < own1;
-        const double2 val = mine ? v[g].q : make_double2(0.0, 0.0);
-        buf[4 + 2 * k] = val.x;
-        buf[5 + 2 * k] = val.y;
-    }
+    halo_qslot[i] = slot;
 }
 
-void fused_pack(const double *part, int nPart, int32_t stride, const Rqp *v, const int32_t *iface, int32_t n_iface,
-                int32_t own0, int32_t own1, double *buf, hipStream_t s)
+void comm_slots(const int32_t *iface, int32_t n_iface, int32_t own0, int32_t own1, const int32_t *halo_g,
+                int64_t halo_total, int64_t N, int32_t *own_qslot, int32_t *halo_qslot, hipStream_t s)
 {
-    int grid = (n_iface + 255) / 256;
-    grid = grid < 1 ? 1 : (grid > 256 ? 256 : grid);
-    k_fused_pack<<<grid, 256, 0, s>>>(part, nPart, stride, v, iface, n_iface, own0, own1, buf);
-}
-
-__global__ void __launch_bounds__(256) k_fused_unpack(const double *buf, const int32_t *iface, int32_t n_iface,
-                                                      int32_t own0, int32_t own1, Rqp *v)
-{
-    for (int32_t k = blockIdx.x * 256 + threadIdx.x; k < n_iface; k += gridDim.x * 256) {
-        const int32_t g = iface[k];
-        if (g < own0 || g >= own1) v[g].q = make_double2(buf[4 + 2 * k], buf[5 + 2 * k]);
-    }
-}
-
-void fused_unpack(const double *buf, const int32_t *iface, int32_t n_iface, int32_t own0, int32_t own1, Rqp *v,
-                  hipStream_t s)
-{
-    if (n_iface <= 0) return;
-    int grid = (n_iface + 255) / 256;
-    grid = grid > 256 ? 256 : grid;
-    k_fused_unpack<<<grid, 256, 0, s>>>(buf, iface, n_iface, own0, own1, v);
+    (void)hipMemsetAsync(own_qslot, 0xff, 4 * (size_t)N, s);
+    if (n_iface > 0) k_own_qslot<<<(n_iface + 255) / 256, 256, 0, s>>>(iface, n_iface, own0, own1, own_qslot);
+    if (halo_total > 0)
+        k_halo_qslot<<<(unsigned)((halo_total + 255) / 256), 256, 0, s>>>(halo_g, halo_total, iface, n_iface, own0, own1,
+                                                                          halo_qslot);
 }
 
 // ================================================================= fp32 leg ===

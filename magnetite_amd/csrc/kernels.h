@@ -236,12 +236,17 @@ struct FusedParams {
     int32_t part_stride_in; // ... and in part_in (1 when the sums arrive all-reduced)
     FusedState *st;
     double *hist;
+    // multi-GPU exchange (all null on one GPU): see k_cg_fused
+    const int32_t *own_qslot;  // N
+    const int32_t *halo_qslot; // halo_total
+    const double2 *comm_in_q;  // n_iface, all-reduced q of iterate j-1
+    double2 *comm_out_q;       // n_iface, this rank's q of iterate j (zeros where it is not the owner)
 };
 void tile_meta(const int32_t *tile_deg, const int64_t *tile_off, const int32_t *tile_hoff, int32_t T, TileMeta *meta,
                hipStream_t s);
 // workgroups of the fused kernel: all co-resident (occupancy query x CUs), so the launch is one persistent round --
 // measured best on MI355X (fewer, fatter workgroups also mean fewer dot partials for every workgroup to reduce)
-int fused_grid(int32_t B, int32_t cap, int32_t tiles);
+int fused_grid(int32_t B, int32_t cap, int32_t tiles, bool comm);
 void fused_launch(const FusedParams &P, int32_t B, int32_t grid, hipStream_t s);
 // in[node] = {-b, 0, 0}; part[0..] = {b.b partials over owned tiles, 1/grid, 0, 0} so that launch 0 gets
 // alpha finite, beta = 1
@@ -249,11 +254,9 @@ void fused_init(const double2 *bP, Rqp *in, Rqp *out, int64_t N, int32_t B, int3
                 double *part, int32_t stride, int32_t grid, hipStream_t s);
 void fused_setup(const double *part, int32_t nPart, int32_t stride, int stop_mode, double tol, long long max_iter,
                  FusedState *st, hipStream_t s);
-// multi-GPU: buf = [4 dot sums | q on owned interface nodes]; unpack writes q of the others into out[g].q
-void fused_pack(const double *part, int nPart, int32_t stride, const Rqp *v, const int32_t *iface, int32_t n_iface,
-                int32_t own0, int32_t own1, double *buf, hipStream_t s);
-void fused_unpack(const double *buf, const int32_t *iface, int32_t n_iface, int32_t own0, int32_t own1, Rqp *v,
-                  hipStream_t s);
+// multi-GPU: slot tables of the exchange buffer [4 x g_all dot partials | q of the n_iface interface nodes]
+void comm_slots(const int32_t *iface, int32_t n_iface, int32_t own0, int32_t own1, const int32_t *halo_g,
+                int64_t halo_total, int64_t N, int32_t *own_qslot, int32_t *halo_qslot, hipStream_t s);
 
 // ---- fp32 leg of BASELINE config 5 (fp64 vs fp32 CG tolerance sweep): the fused iteration with the CG state, the
 // operator arithmetic and TILE-RELATIVE coordinates in fp32; dot products accumulate in fp64 ----

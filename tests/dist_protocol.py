@@ -4,7 +4,13 @@ rows of K_ff (oracle CSR); per iteration exactly the library's two collectives a
     all_reduce([p.q partial])                       after the operator
     all_reduce([r.r partial | r on interface nodes]) after the update
 ghost p is advanced locally from the exchanged r (p = -r + beta p), and the solution is assembled by a final
-all-reduce.  Checks the result against the single-process oracle CG."""
+all-reduce.  Checks the result against the single-process oracle CG.
+
+`--fused` restates the default one-launch iteration instead (cg_phase_fused / k_cg_fused<COMM>): ONE in-place
+all-reduce per iteration on a parity-double-buffered exchange buffer
+    [r.r | p.q | r.q | q.q partials, G slots each, summed slot by slot | q on interface nodes (owner's value, 0 elsewhere)]
+launch j reads the all-reduced buffer [j & 1] (sums and ghost q of iterate j-1), advances owned and ghost records,
+and fills buffer [(j & 1) ^ 1]; beta's numerator is expanded from the exact sums of the previous iterate."""
 import os
 import sys
 
@@ -60,6 +66,11 @@ def main():
         dist.all_reduce(t)
         return v
 
+    if "--fused" in sys.argv:
+        it, x = fused_protocol(K.n, b, Arows, mine, iface_dofs, iface_mine, rank, allreduce)
+        finish(p, free, x, mine, it, iface, rank, world, allreduce)
+        return
+
     x = np.zeros(K.n)
     r = -b.copy()                                  # every rank starts from the full right-hand side
     pp = np.zeros(K.n)
@@ -85,6 +96,13 @@ def main():
         r[notmine_if] = buf[1:][~iface_mine]
         rr_prev, rr, pp = rr, buf[0], pn
         it += 1
+    finish(p, free, x, mine, it, iface, rank, world, allreduce)
+
+
+def finish(p, free, x, mine, it, iface, rank, world, allreduce):
+    import torch.distributed as dist
+
+    import oracle
     x[~mine] = 0.0
     allreduce(x)
     u = np.where(free, x, p.u_in)
@@ -96,6 +114,56 @@ def main():
     ok = err <= 1e-8 and abs(it - ref["iterations"]) <= max(3, ref["iterations"] // 50) and iface.size > 0
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)
+
+
+def fused_protocol(n, b, Arows, mine, iface_dofs, iface_mine, rank, allreduce, target=1e-4, G=4):
+    """Records {r, q, p} of iterate j-1 -> iterate j in one step per iteration, as k_cg_fused<COMM> does."""
+    own_if = iface_dofs[iface_mine]                # interface DOFs this rank owns: their q goes into the buffer
+    ghost_if = iface_dofs[~iface_mine]             # ... owned elsewhere: their q comes out of it
+    nq = iface_dofs.size
+    cbuf = [np.zeros(4 * G + nq), np.zeros(4 * G + nq)]
+    grid = 1 + rank % G                            # ranks may run different grids: unused slots are written as zeros
+    r, q, pp, x = -b.copy(), np.zeros(n), np.zeros(n), np.zeros(n)
+
+    def partials(v):                               # `grid` partial sums in slots [0, grid), zeros above
+        out = np.zeros(G)
+        for k, chunk in enumerate(np.array_split(v, grid)):
+            out[k] = chunk.sum()
+        return out
+
+    c0 = cbuf[0]
+    c0[0:G] = partials(b[mine] * b[mine])          # fused_init: b.b partials, "p.q" = 1 on slot 0
+    c0[G] = 1.0
+    allreduce(c0)
+    j = 0
+    while j < 200000:
+        cin, cout = cbuf[j & 1], cbuf[(j & 1) ^ 1]
+        S = [cin[c * G:(c + 1) * G].sum() for c in range(4)]
+        rr = S[0]
+        it_done = j - 1
+        if it_done >= 1 and np.sqrt(rr) <= target:
+            return it_done, x
+        alpha = rr / S[1]
+        beta = (rr + 2.0 * alpha * S[2] + alpha * alpha * S[3]) / rr
+        q[ghost_if] = cin[4 * G:][~iface_mine]     # ghost q of iterate j-1 straight from the exchange buffer
+        upd = np.concatenate([np.where(mine)[0], ghost_if])
+        x[mine] += alpha * pp[mine]
+        r[upd] += alpha * q[upd]
+        pn = np.zeros(n)
+        pn[upd] = -r[upd] + beta * pp[upd]
+        qn = Arows @ pn                            # owned rows only
+        q[mine] = qn
+        pp = pn
+        cout[0 * G:1 * G] = partials(r[mine] * r[mine])
+        cout[1 * G:2 * G] = partials(pn[mine] * qn)
+        cout[2 * G:3 * G] = partials(r[mine] * qn)
+        cout[3 * G:4 * G] = partials(qn * qn)
+        qb = cout[4 * G:]
+        qb[:] = 0.0                                # this rank's zero for interface nodes it does not own
+        qb[iface_mine] = q[own_if]
+        allreduce(cout)
+        j += 1
+    return j, x
 
 
 if __name__ == "__main__":

@@ -8,10 +8,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.mark.parametrize("fused", [False, True], ids=["two-collectives", "fused-exchange-buffer"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_distributed_cg_protocol_over_gloo(built, world):
+def test_distributed_cg_protocol_over_gloo(built, world, fused):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-           "--master-addr", "127.0.0.1", "--master-port", str(29560 + world),
-           os.path.join(ROOT, "tests", "dist_protocol.py")]
+           "--master-addr", "127.0.0.1", "--master-port", str(29560 + world + (10 if fused else 0)),
+           os.path.join(ROOT, "tests", "dist_protocol.py")] + (["--fused"] if fused else [])
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
