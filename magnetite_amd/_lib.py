@@ -34,7 +34,7 @@ class Options(C.Structure):
                 ("cg_operator", C.c_int32), ("assemble_csr", C.c_int32), ("check_every", C.c_int32),
                 ("use_graph", C.c_int32), ("tile_nodes", C.c_int32), ("history_len", C.c_int32),
                 ("verbose", C.c_int32), ("op_variant", C.c_int32), ("cg_variant", C.c_int32), ("precision", C.c_int32),
-                ("reserved", C.c_int32 * 2)]
+                ("preconditioner", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Problem(C.Structure):

@@ -100,12 +100,14 @@ struct mag_ctx {
     // CG (Hilbert numbering)
     DevBuf x, r, p0, p1, q, bP, tmpP, partRR, partPQ, state, hist;
     // fused single-launch variant
-    DevBuf rqp0, rqp1, fpart, fstate, tmeta, comm_f, own_qslot, halo_qslot;
+    DevBuf rqp0, rqp1, fpart, fstate, tmeta, comm_f, own_qslot, halo_qslot, minvP, halo_minv;
     magk::FusedState *h_fstate = nullptr; // pinned, 3 slots
     bool fused = false;
     int32_t fgrid = 1; // workgroups of the fused kernel for this problem
     int32_t g_all = 1; // ... of the rank with the most tiles: dot-partial slots of the exchange buffer (multi-GPU)
-    size_t cwords = 0; // doubles per exchange buffer: 4 * g_all + 2 * n_iface
+    size_t cwords = 0; // doubles per exchange buffer: nsums * g_all + 2 * n_iface
+    bool pre = false;  // mag_options.preconditioner != 0
+    int nsums() const { return pre ? 5 : 4; }
     DevBuf xy32, hxy32, rqp32a, rqp32b, x32; // fp32 leg (mag_options.precision = 1)
     hipGraphExec_t graph = nullptr;
     struct GraphKey {
@@ -713,17 +715,21 @@ magk::FusedParams fused_params(mag_ctx *ctx, int par)
         P.nPart = ctx->g_all;
         P.part_out = cout;
         P.part_stride = ctx->g_all;
-        P.comm_in_q = (const double2 *)(cin + 4 * (size_t)ctx->g_all);
-        P.comm_out_q = (double2 *)(cout + 4 * (size_t)ctx->g_all);
+        P.comm_in_q = (const double2 *)(cin + (size_t)ctx->nsums() * ctx->g_all);
+        P.comm_out_q = (double2 *)(cout + (size_t)ctx->nsums() * ctx->g_all);
         P.own_qslot = ctx->own_qslot.as<int32_t>();
         P.halo_qslot = ctx->halo_qslot.as<int32_t>();
     } else {
         double *part = ctx->fpart.as<double>();
-        P.part_out = part + (size_t)(par ^ 1) * 4 * stride;
+        P.part_out = part + (size_t)(par ^ 1) * 5 * stride;
         P.part_stride = stride;
-        P.part_in = part + (size_t)par * 4 * stride;
+        P.part_in = part + (size_t)par * 5 * stride;
         P.part_stride_in = stride;
         P.nPart = ctx->fgrid;
+    }
+    if (ctx->pre) {
+        P.minvP = ctx->minvP.as<float4>();
+        P.halo_minv = ctx->halo_minv.as<float4>();
     }
     P.st = ctx->fstate.as<magk::FusedState>();
     P.hist = ctx->hist.as<double>();
@@ -751,9 +757,20 @@ int reserve_fused(mag_ctx *ctx)
 {
     HIPCHK(ctx->rqp0.reserve(sizeof(magk::Rqp) * (size_t)ctx->N));
     HIPCHK(ctx->rqp1.reserve(sizeof(magk::Rqp) * (size_t)ctx->N));
-    HIPCHK(ctx->fpart.reserve(8 * 2 * 4 * (size_t)magk::kMaxGrid));
+    HIPCHK(ctx->fpart.reserve(8 * 2 * 5 * (size_t)magk::kMaxGrid));
     HIPCHK(ctx->fstate.reserve(sizeof(magk::FusedState)));
-    ctx->fgrid = magk::fused_grid(ctx->B, ctx->cap, ctx->t1 - ctx->t0, ctx->dist);
+    ctx->pre = ctx->opt.preconditioner != 0;
+    if (ctx->pre) {
+        // M = node-diagonal blocks of K_ff, inverted once per solve (16 bytes per node + per halo entry)
+        HIPCHK(ctx->minvP.reserve(16 * (size_t)ctx->N));
+        HIPCHK(ctx->halo_minv.reserve(16 * (size_t)std::max<int64_t>(ctx->halo_total, 1)));
+        magk::precond_blocks(ctx->inc_off.as<int32_t>(), ctx->inc.as<uint32_t>(), ctx->perm.as<uint32_t>(),
+                             ctx->conn.as<int32_t>(), ctx->xy.as<double>(), ctx->uknown.as<uint8_t>(), ctx->N, ctx->nu,
+                             ctx->youngs, ctx->thick, ctx->opt.preconditioner, ctx->minvP.as<float4>(), ctx->stream);
+        magk::halo_minv(ctx->halo_g.as<int32_t>(), ctx->minvP.as<float4>(), ctx->halo_total,
+                        ctx->halo_minv.as<float4>(), ctx->stream);
+    }
+    ctx->fgrid = magk::fused_grid(ctx->B, ctx->cap, ctx->t1 - ctx->t0, ctx->dist, ctx->pre);
     if (ctx->dist) {
         // every rank computes the same g_all: same device, same cap, tile counts from the same arithmetic
         const int R = ctx->comm.nranks;
@@ -762,8 +779,8 @@ int reserve_fused(mag_ctx *ctx)
             const int32_t n = (int32_t)(((int64_t)ctx->T * (r + 1)) / R - ((int64_t)ctx->T * r) / R);
             most = std::max(most, n);
         }
-        ctx->g_all = magk::fused_grid(ctx->B, ctx->cap, most, true);
-        ctx->cwords = 4 * (size_t)ctx->g_all + 2 * (size_t)ctx->n_iface;
+        ctx->g_all = magk::fused_grid(ctx->B, ctx->cap, most, true, ctx->pre);
+        ctx->cwords = (size_t)ctx->nsums() * ctx->g_all + 2 * (size_t)ctx->n_iface;
         HIPCHK(ctx->comm_f.reserve(8 * 2 * ctx->cwords + 64));
         HIPCHK(ctx->own_qslot.reserve(4 * (size_t)ctx->N));
         HIPCHK(ctx->halo_qslot.reserve(4 * (size_t)std::max<int64_t>(ctx->halo_total, 1)));
@@ -779,7 +796,8 @@ int ensure_fused_graph(mag_ctx *ctx, int G)
     mag_ctx::GraphKey k = {};
     void *ptrs[] = {ctx->x.p,   ctx->rqp0.p,  ctx->rqp1.p,     ctx->fpart.p,  ctx->fstate.p, ctx->hist.p,
                     ctx->xyP.p, ctx->maskP.p, ctx->tmeta.p,    ctx->ell.p,    ctx->halo_g.p, ctx->halo_xy.p,
-                    ctx->iface.p, (void *)(intptr_t)ctx->cap, (void *)(intptr_t)(1 + ctx->fgrid) /* fused */};
+                    ctx->iface.p, (void *)(intptr_t)ctx->cap, (void *)(intptr_t)(1 + ctx->fgrid) /* fused */,
+                    ctx->pre ? ctx->minvP.p : nullptr, ctx->pre ? ctx->halo_minv.p : nullptr};
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); ++i) k.ptrs[i] = ptrs[i];
     k.N = ctx->N;
     k.T = ctx->T;
@@ -821,16 +839,17 @@ int cg_phase_fused(mag_ctx *ctx)
         // b.b partials go straight into exchange buffer 0 (its q part = q_{-1} = 0), summed over ranks in place
         double *c0 = ctx->comm_f.as<double>();
         HIPCHK(hipMemsetAsync(c0, 0, 8 * 2 * ctx->cwords, s));
-        magk::fused_init(ctx->bP.as<double2>(), ctx->rqp0.as<magk::Rqp>(), ctx->rqp1.as<magk::Rqp>(), ctx->N, ctx->B,
-                         ctx->T, ctx->t0, ctx->t1, c0, ctx->g_all, ctx->fgrid, s);
+        magk::fused_init(ctx->bP.as<double2>(), ctx->pre ? ctx->minvP.as<float4>() : nullptr, ctx->rqp0.as<magk::Rqp>(),
+                         ctx->rqp1.as<magk::Rqp>(), ctx->N, ctx->B, ctx->T, ctx->t0, ctx->t1, c0, ctx->g_all, ctx->fgrid, s);
         std::string msg;
         if (int rc = ctx->comm.allreduce_sum(c0, (int64_t)ctx->cwords, s, msg)) return fail(ctx, rc, "%s", msg.c_str());
         magk::fused_setup(c0, ctx->g_all, ctx->g_all, ctx->opt.stop_mode, ctx->opt.tol, (long long)ctx->opt.max_iter,
                           ctx->fstate.as<FusedState>(), s);
     } else {
-        HIPCHK(hipMemsetAsync(ctx->fpart.p, 0, 8 * 2 * 4 * (size_t)stride, s));
-        magk::fused_init(ctx->bP.as<double2>(), ctx->rqp0.as<magk::Rqp>(), ctx->rqp1.as<magk::Rqp>(), ctx->N, ctx->B,
-                         ctx->T, ctx->t0, ctx->t1, ctx->fpart.as<double>(), stride, ctx->fgrid, s);
+        HIPCHK(hipMemsetAsync(ctx->fpart.p, 0, 8 * 2 * 5 * (size_t)stride, s));
+        magk::fused_init(ctx->bP.as<double2>(), ctx->pre ? ctx->minvP.as<float4>() : nullptr, ctx->rqp0.as<magk::Rqp>(),
+                         ctx->rqp1.as<magk::Rqp>(), ctx->N, ctx->B, ctx->T, ctx->t0, ctx->t1, ctx->fpart.as<double>(),
+                         stride, ctx->fgrid, s);
         magk::fused_setup(ctx->fpart.as<double>(), ctx->fgrid, stride, ctx->opt.stop_mode, ctx->opt.tol,
                           (long long)ctx->opt.max_iter, ctx->fstate.as<FusedState>(), s);
     }
@@ -1092,6 +1111,7 @@ void mag_default_options(mag_options *o)
     o->op_variant = 0;
     o->cg_variant = 1;
     o->precision = 0;
+    o->preconditioner = 0;
 }
 
 mag_ctx *mag_create(const mag_options *opt)
@@ -1104,6 +1124,7 @@ mag_ctx *mag_create(const mag_options *opt)
         mag_default_options(&ctx->opt);
     mag_options &o = ctx->opt;
     if (o.tile_nodes != 256 && o.tile_nodes != 512 && o.tile_nodes != 1024) o.tile_nodes = 0; // 0 = automatic
+    if (o.preconditioner < 0 || o.preconditioner > 2) o.preconditioner = 0;
     if (o.check_every < 2) o.check_every = 2;
     if (o.check_every & 1) ++o.check_every; // p ping-pong parity must restart at 0 every block
     if (o.check_every > 4096) o.check_every = 4096;
@@ -1148,7 +1169,7 @@ void mag_destroy(mag_ctx *ctx)
                           &ctx->val_ff, &ctx->b_ff, &ctx->rp_full, &ctx->col_full, &ctx->x, &ctx->r, &ctx->p0,
                           &ctx->p1, &ctx->q, &ctx->bP, &ctx->tmpP, &ctx->partRR, &ctx->partPQ, &ctx->state,
                           &ctx->hist, &ctx->u, &ctx->f, &ctx->stress, &ctx->rqp0, &ctx->rqp1, &ctx->fpart, &ctx->fstate,
-                          &ctx->tmeta, &ctx->comm_f, &ctx->own_qslot, &ctx->halo_qslot, &ctx->xy32, &ctx->hxy32, &ctx->rqp32a, &ctx->rqp32b, &ctx->x32};
+                          &ctx->tmeta, &ctx->comm_f, &ctx->own_qslot, &ctx->halo_qslot, &ctx->minvP, &ctx->halo_minv, &ctx->xy32, &ctx->hxy32, &ctx->rqp32a, &ctx->rqp32b, &ctx->x32};
         for (DevBuf *b : bufs) b->release();
         if (ctx->h_state) (void)hipHostFree(ctx->h_state);
         if (ctx->h_fstate) (void)hipHostFree(ctx->h_fstate);
@@ -1276,6 +1297,10 @@ int mag_run(mag_ctx *ctx)
     HIPCHK(ctx->stress.reserve(8 * (size_t)E));
     const bool csr_op = ctx->opt.cg_operator == MAG_OP_CSR;
     const bool f32 = ctx->opt.precision == 1;
+    if (ctx->opt.preconditioner != 0 && (csr_op || f32 || !ctx->fused))
+        return fail(ctx, MAG_ERR_BAD_ARGS,
+                    "preconditioner needs the fused LDS iteration: cg_variant 1, precision fp64, matrix-free operator, "
+                    "every tile within LDS");
     if (int rc = csr_op ? cg_phase_csr(ctx)
                         : (f32 ? cg_phase_fused32(ctx) : (ctx->fused ? cg_phase_fused(ctx) : cg_phase(ctx))))
         return rc;
@@ -1464,12 +1489,10 @@ int mag_time_operator(mag_ctx *ctx, int32_t reps, double *ms_per_launch)
         h.max_iter = (long long)1 << 60;
         HIPCHK(hipMemcpyAsync(ctx->fstate.p, &h, sizeof h, hipMemcpyHostToDevice, s));
         const int32_t stride = magk::kMaxGrid;
-        HIPCHK(hipMemsetAsync(ctx->fpart.p, 0, 8 * 2 * 4 * (size_t)stride, s));
+        HIPCHK(hipMemsetAsync(ctx->fpart.p, 0, 8 * 2 * 5 * (size_t)stride, s));
         const double one = 1.0;
-        for (int par = 0; par < 2; ++par)
-            for (int c = 0; c < 2; ++c)
-                HIPCHK(hipMemcpyAsync(ctx->fpart.as<double>() + (size_t)par * 4 * stride + (size_t)c * stride, &one, 8,
-                                      hipMemcpyHostToDevice, s));
+        for (int c = 0; c < (ctx->pre ? 3 : 2); ++c) // {r.r, p.q[, rho]} = 1, the rest 0
+            HIPCHK(hipMemcpyAsync(ctx->fpart.as<double>() + (size_t)c * stride, &one, 8, hipMemcpyHostToDevice, s));
         magk::FusedParams P = fused_params(ctx, 0);
         P.hist_len = 0;
         P.part_out = ctx->partRR.as<double>(); // scratch: keep {1,1,0,0} in place for every launch

@@ -875,8 +875,11 @@ void expand_free(const double *xf, const int32_t *fidx, const uint8_t *u_known, 
 // State machine shared by the fused iteration kernels: judge iterate j-1 from its exact dots S (identical in every
 // workgroup), let workgroup 0 record the verdict, and derive this launch's alpha and beta.  Returns false when the
 // solve is over (converged / iteration cap / non-finite residual): x and r of iterate j-1 are then already in place.
+// NS = 5 is the preconditioned iteration (k_cg_fused<.., PRE>): S = {r.r, p.q, r.z, q.z, q.Minv q} with z = Minv r;
+// rho = r.z takes the place of r.r in alpha and beta, the stop test stays on the true residual norm.
+template <int NS>
 __device__ inline bool fused_step(FusedState *st, int par, long long j, double target, long long max_iter, int stop_mode,
-                                  const double (&S)[4], double *hist, int hist_len, double &alpha, double &beta)
+                                  const double (&S)[NS], double *hist, int hist_len, double &alpha, double &beta)
 {
     const double rr = S[0]; // |r_{j-1}|^2, exact
     const double cost = stop_mode == 1 ? fabs(rr) : sqrt(rr);
@@ -897,27 +900,28 @@ __device__ inline bool fused_step(FusedState *st, int par, long long j, double t
         }
     }
     if (finished || broke || maxed) return false;
-    alpha = rr / S[1];
-    beta = (rr + 2.0 * alpha * S[2] + alpha * alpha * S[3]) / rr;
+    const double rho = NS == 5 ? S[2] : rr;
+    alpha = rho / S[1];
+    beta = (rho + 2.0 * alpha * S[NS - 2] + alpha * alpha * S[NS - 1]) / rho;
     return true;
 }
 
-template <int B>
-__device__ inline void block_sum4(double (&v)[4], double *s_red)
+template <int B, int NS>
+__device__ inline void block_sumN(double (&v)[NS], double *s_red)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] += __shfl_down(v[c], off);
+        for (int c = 0; c < NS; ++c) v[c] += __shfl_down(v[c], off);
     }
     __syncthreads();
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) s_red[c * (B / 64) + (threadIdx.x >> 6)] = v[c];
+        for (int c = 0; c < NS; ++c) s_red[c * (B / 64) + (threadIdx.x >> 6)] = v[c];
     }
     __syncthreads();
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < NS; ++c) {
         double t = 0.0;
 #pragma unroll
         for (int i = 0; i < B / 64; ++i) t += s_red[c * (B / 64) + i];
@@ -925,13 +929,31 @@ __device__ inline void block_sum4(double (&v)[4], double *s_red)
     }
 }
 
+template <int B>
+__device__ inline void block_sum4(double (&v)[4], double *s_red)
+{
+    block_sumN<B, 4>(v, s_red);
+}
+
+// z = Minv r for one node: Minv = (i00, i01, i11) in fp32 (symmetric 2x2; i01 = 0 for plain Jacobi)
+__device__ inline double2 apply_minv(const float4 mi, const double2 r)
+{
+    double2 z;
+    z.x = (double)mi.x * r.x + (double)mi.y * r.y;
+    z.y = (double)mi.y * r.x + (double)mi.z * r.y;
+    return z;
+}
+
 // COMM (multi-GPU): the launch reads the all-reduced exchange buffer of the previous iteration directly (dot partials
 // summed over ranks slot by slot, q of interface nodes other ranks own) and writes its own contribution to the next
 // one (partials, q of the interface nodes it owns, zeros elsewhere), so a distributed iteration is this kernel plus
 // ONE in-place all-reduce -- no pack/unpack launches.
-template <int B, bool WT, bool COMM>
+// PRE (opt-in, mag_options.preconditioner): Jacobi / 2x2 block-Jacobi preconditioned CG, p_j = -Minv r_j + beta p;
+// every tile applies Minv to its owned AND halo nodes (inverse blocks in fp32, 16 bytes per node), five sums.
+template <int B, bool WT, bool COMM, bool PRE>
 __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
 {
+    constexpr int NS = PRE ? 5 : 4;
     extern __shared__ __attribute__((aligned(16))) double2 smem[];
     double2 *s_xy = smem;
     double2 *s_p = smem + P.cap;
@@ -951,6 +973,7 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
     double2 ca, ar, aq, ap, xo, hc, hr, hq, hp;
     uint8_t m = 3;
     int32_t deg = 0, nh = 0, hoff = 0, hg = 0, oslot = -1;
+    float4 mi = make_float4(0.f, 0.f, 0.f, 0.f), hmi = mi;
     uint32_t w[kSlotRegs];
     const uint32_t *ell = nullptr;
     auto load_tile = [&](int32_t t) {
@@ -969,6 +992,7 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
             ca = P.xyP[node];
             m = P.maskP[node];
             if (COMM) oslot = P.own_qslot[node];
+            if (PRE) mi = P.minvP[node];
         }
         deg = tm.deg;
         ell = P.ell16 + tm.ell_off + tid;
@@ -981,6 +1005,7 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
         if (hvalid) {
             hg = P.halo_g[hoff + tid];
             hc = P.halo_xy[hoff + tid];
+            if (PRE) hmi = P.halo_minv[hoff + tid];
             const Rqp rec = P.in[hg];
             hr = rec.r;
             hq = rec.q;
@@ -994,26 +1019,27 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
     load_tile(P.t0 + blockIdx.x);
 
     // ---- dots of iterate j-1
-    double S[4] = {0.0, 0.0, 0.0, 0.0};
+    double S[NS] = {};
     for (int i = tid; i < P.nPart; i += B) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) S[c] += P.part_in[c * P.part_stride_in + i];
+        for (int c = 0; c < NS; ++c) S[c] += P.part_in[c * P.part_stride_in + i];
     }
-    block_sum4<B>(S, s_red);
+    block_sumN<B, NS>(S, s_red);
     if (was_done) return;
     double alpha = 0.0, beta = 0.0;
-    if (!fused_step(st, P.par, j, target, max_iter, stop_mode, S, P.hist, P.hist_len, alpha, beta)) return;
+    if (!fused_step<NS>(st, P.par, j, target, max_iter, stop_mode, S, P.hist, P.hist_len, alpha, beta)) return;
 
     const double c0 = P.c0, nu = P.nu, h = P.h;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    double acc[NS] = {};
     int32_t t = P.t0 + blockIdx.x;
     for (;;) {
         // r_j, x_j, p_j of the owned node
         double2 rn, pn;
         rn.x = ar.x + alpha * aq.x;
         rn.y = ar.y + alpha * aq.y;
-        pn.x = -rn.x + beta * ap.x;
-        pn.y = -rn.y + beta * ap.y;
+        const double2 zn = PRE ? apply_minv(mi, rn) : rn;
+        pn.x = -zn.x + beta * ap.x;
+        pn.y = -zn.y + beta * ap.y;
         xo.x += alpha * ap.x;
         xo.y += alpha * ap.y;
         __syncthreads(); // previous tile's readers are done with the LDS images
@@ -1023,8 +1049,9 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
             double2 hrn, hpn;
             hrn.x = hr.x + alpha * hq.x;
             hrn.y = hr.y + alpha * hq.y;
-            hpn.x = -hrn.x + beta * hp.x;
-            hpn.y = -hrn.y + beta * hp.y;
+            const double2 hzn = PRE ? apply_minv(hmi, hrn) : hrn;
+            hpn.x = -hzn.x + beta * hp.x;
+            hpn.y = -hzn.y + beta * hp.y;
             s_xy[B + tid] = hc;
             s_p[B + tid] = hpn;
         }
@@ -1039,8 +1066,9 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
             double2 hrn, hpn;
             hrn.x = rec.r.x + alpha * hq2.x;
             hrn.y = rec.r.y + alpha * hq2.y;
-            hpn.x = -hrn.x + beta * rec.p.x;
-            hpn.y = -hrn.y + beta * rec.p.y;
+            const double2 hzn = PRE ? apply_minv(P.halo_minv[hoff + hh], hrn) : hrn;
+            hpn.x = -hzn.x + beta * rec.p.x;
+            hpn.y = -hzn.y + beta * rec.p.y;
             s_xy[B + hh] = P.halo_xy[hoff + hh];
             s_p[B + hh] = hpn;
         }
@@ -1073,8 +1101,15 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
             if (COMM && oslot >= 0) P.comm_out_q[oslot] = make_double2(fx, fy);
             acc[0] += rn.x * rn.x + rn.y * rn.y;
             acc[1] += pn.x * fx + pn.y * fy;
-            acc[2] += rn.x * fx + rn.y * fy;
-            acc[3] += fx * fx + fy * fy;
+            if (PRE) {
+                const double2 zq = apply_minv(mi, make_double2(fx, fy));
+                acc[2] += rn.x * zn.x + rn.y * zn.y;
+                acc[NS - 2] += fx * zn.x + fy * zn.y;
+                acc[NS - 1] += fx * zq.x + fy * zq.y;
+            } else {
+                acc[2] += rn.x * fx + rn.y * fy;
+                acc[3] += fx * fx + fy * fy;
+            }
         }
         t += gridDim.x;
         if (t >= P.t1) break;
@@ -1091,8 +1126,9 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
                 double2 rn, pn;
                 rn.x = rec.r.x + alpha * qg.x;
                 rn.y = rec.r.y + alpha * qg.y;
-                pn.x = -rn.x + beta * rec.p.x;
-                pn.y = -rn.y + beta * rec.p.y;
+                const double2 zg = PRE ? apply_minv(P.minvP[g], rn) : rn;
+                pn.x = -zg.x + beta * rec.p.x;
+                pn.y = -zg.y + beta * rec.p.y;
                 P.out[g].r = rn;
                 P.out[g].p = pn;
                 P.comm_out_q[k] = make_double2(0.0, 0.0);
@@ -1102,20 +1138,21 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
         if (blockIdx.x == 0) {
             for (int32_t i = gridDim.x + tid; i < P.part_stride; i += B) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) P.part_out[c * P.part_stride + i] = 0.0;
+                for (int c = 0; c < NS; ++c) P.part_out[c * P.part_stride + i] = 0.0;
             }
         }
     }
-    block_sum4<B>(acc, s_red);
+    block_sumN<B, NS>(acc, s_red);
     if (tid == 0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) P.part_out[c * P.part_stride + blockIdx.x] = acc[c];
+        for (int c = 0; c < NS; ++c) P.part_out[c * P.part_stride + blockIdx.x] = acc[c];
     }
 }
 
-template <int B, bool WT, bool COMM>
-__global__ void __launch_bounds__(B) k_cg_fused_dma(const FusedParams P)
+template <int B, bool WT, bool COMM, bool PRE>
+__global__ void __launch_bounds__(B, 4) k_cg_fused_dma(const FusedParams P)
 {
+    constexpr int NS = PRE ? 5 : 4;
     extern __shared__ __attribute__((aligned(16))) double2 smem[];
     double2 *s_xy = smem;
     double2 *s_p = smem + P.cap;
@@ -1125,7 +1162,7 @@ __global__ void __launch_bounds__(B) k_cg_fused_dma(const FusedParams P)
     // 1-KiB pieces into a wave-private stage and each lane picks its 48-byte record out of LDS (stride 3 x 16 B:
     // conflict-free); a per-lane 48-byte-stride global access streams ~20 % slower.  Halo records are gathered by
     // DMA too (per-lane source address, lane-linear destination).
-    double2 *s_stage_all = (double2 *)(s_red + 4 * (B / 64));
+    double2 *s_stage_all = (double2 *)(s_red + (PRE ? 6 : 4) * (B / 64)); // 6, not 5: keeps the 16-byte alignment
     double2 *s_stage = s_stage_all + (threadIdx.x >> 6) * 192;
     double2 *s_hr = s_stage_all + 3 * B, *s_hq = s_hr + B, *s_hp = s_hq + B;
     typedef __attribute__((address_space(3))) void lds_void;
@@ -1149,6 +1186,7 @@ __global__ void __launch_bounds__(B) k_cg_fused_dma(const FusedParams P)
     double2 xo;
     uint8_t m = 3;
     int32_t deg = 0, nh = 0, hoff = 0, oslot = -1;
+    float4 mi = make_float4(0.f, 0.f, 0.f, 0.f), hmi = mi;
     uint32_t w[kSlotRegs];
     const uint32_t *ell = nullptr;
     // callers guarantee that no wave still reads s_xy / the stages of the previous tile (barrier before the call)
@@ -1176,12 +1214,14 @@ __global__ void __launch_bounds__(B) k_cg_fused_dma(const FusedParams P)
             xo = P.x[node];
             m = P.maskP[node];
             if (COMM) oslot = P.own_qslot[node];
+            if (PRE) mi = P.minvP[node];
         }
         deg = tm.deg;
         ell = P.ell16 + tm.ell_off + tid;
 #pragma unroll
         for (int k = 0; k < kSlotRegs; ++k) w[k] = k < deg ? ell[(int64_t)k * B] : 0xffffffffu;
         if (hvalid) {
+            if (PRE) hmi = P.halo_minv[hoff + tid];
             __builtin_amdgcn_global_load_lds((glb_void *)(P.halo_xy + hoff + tid), (lds_void *)(s_xy + B + wv * 64), 16, 0, 0);
             const double2 *src = (const double2 *)(P.in + hg);
             const double2 *qsrc = src + 1;
@@ -1197,18 +1237,18 @@ __global__ void __launch_bounds__(B) k_cg_fused_dma(const FusedParams P)
     load_tile(P.t0 + blockIdx.x);
 
     // ---- dots of iterate j-1
-    double S[4] = {0.0, 0.0, 0.0, 0.0};
+    double S[NS] = {};
     for (int i = tid; i < P.nPart; i += B) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) S[c] += P.part_in[c * P.part_stride_in + i];
+        for (int c = 0; c < NS; ++c) S[c] += P.part_in[c * P.part_stride_in + i];
     }
-    block_sum4<B>(S, s_red);
+    block_sumN<B, NS>(S, s_red);
     if (was_done) return;
     double alpha = 0.0, beta = 0.0;
-    if (!fused_step(st, P.par, j, target, max_iter, stop_mode, S, P.hist, P.hist_len, alpha, beta)) return;
+    if (!fused_step<NS>(st, P.par, j, target, max_iter, stop_mode, S, P.hist, P.hist_len, alpha, beta)) return;
 
     const double c0 = P.c0, nu = P.nu, h = P.h;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    double acc[NS] = {};
     int32_t t = P.t0 + blockIdx.x;
     for (;;) {
         // this wave's DMA has landed: pick the lane's record (r, q, p of iterate j-1) and coordinates out of LDS
@@ -1220,8 +1260,9 @@ __global__ void __launch_bounds__(B) k_cg_fused_dma(const FusedParams P)
         double2 rn, pn;
         rn.x = ar.x + alpha * aq.x;
         rn.y = ar.y + alpha * aq.y;
-        pn.x = -rn.x + beta * ap.x;
-        pn.y = -rn.y + beta * ap.y;
+        const double2 zn = PRE ? apply_minv(mi, rn) : rn;
+        pn.x = -zn.x + beta * ap.x;
+        pn.y = -zn.y + beta * ap.y;
         xo.x += alpha * ap.x;
         xo.y += alpha * ap.y;
         s_p[tid] = pn;
@@ -1230,8 +1271,9 @@ __global__ void __launch_bounds__(B) k_cg_fused_dma(const FusedParams P)
             double2 hrn, hpn;
             hrn.x = hr.x + alpha * hq.x;
             hrn.y = hr.y + alpha * hq.y;
-            hpn.x = -hrn.x + beta * hp.x;
-            hpn.y = -hrn.y + beta * hp.y;
+            const double2 hzn = PRE ? apply_minv(hmi, hrn) : hrn;
+            hpn.x = -hzn.x + beta * hp.x;
+            hpn.y = -hzn.y + beta * hp.y;
             s_p[B + tid] = hpn;
         }
         for (int32_t hh = tid + B; hh < nh; hh += B) { // more halo nodes than threads (rare)
@@ -1245,8 +1287,9 @@ __global__ void __launch_bounds__(B) k_cg_fused_dma(const FusedParams P)
             double2 hrn, hpn;
             hrn.x = rec.r.x + alpha * hq2.x;
             hrn.y = rec.r.y + alpha * hq2.y;
-            hpn.x = -hrn.x + beta * rec.p.x;
-            hpn.y = -hrn.y + beta * rec.p.y;
+            const double2 hzn = PRE ? apply_minv(P.halo_minv[hoff + hh], hrn) : hrn;
+            hpn.x = -hzn.x + beta * rec.p.x;
+            hpn.y = -hzn.y + beta * rec.p.y;
             s_xy[B + hh] = P.halo_xy[hoff + hh];
             s_p[B + hh] = hpn;
         }
@@ -1286,8 +1329,15 @@ __global__ void __launch_bounds__(B) k_cg_fused_dma(const FusedParams P)
             if (COMM && oslot >= 0) P.comm_out_q[oslot] = make_double2(fx, fy);
             acc[0] += rn.x * rn.x + rn.y * rn.y;
             acc[1] += pn.x * fx + pn.y * fy;
-            acc[2] += rn.x * fx + rn.y * fy;
-            acc[3] += fx * fx + fy * fy;
+            if (PRE) {
+                const double2 zq = apply_minv(mi, make_double2(fx, fy));
+                acc[2] += rn.x * zn.x + rn.y * zn.y;
+                acc[NS - 2] += fx * zn.x + fy * zn.y;
+                acc[NS - 1] += fx * zq.x + fy * zq.y;
+            } else {
+                acc[2] += rn.x * fx + rn.y * fy;
+                acc[3] += fx * fx + fy * fy;
+            }
         }
         t += gridDim.x;
         if (t >= P.t1) break;
@@ -1305,8 +1355,9 @@ __global__ void __launch_bounds__(B) k_cg_fused_dma(const FusedParams P)
                 double2 rn, pn;
                 rn.x = rec.r.x + alpha * qg.x;
                 rn.y = rec.r.y + alpha * qg.y;
-                pn.x = -rn.x + beta * rec.p.x;
-                pn.y = -rn.y + beta * rec.p.y;
+                const double2 zg = PRE ? apply_minv(P.minvP[g], rn) : rn;
+                pn.x = -zg.x + beta * rec.p.x;
+                pn.y = -zg.y + beta * rec.p.y;
                 P.out[g].r = rn;
                 P.out[g].p = pn;
                 P.comm_out_q[k] = make_double2(0.0, 0.0);
@@ -1316,20 +1367,20 @@ __global__ void __launch_bounds__(B) k_cg_fused_dma(const FusedParams P)
         if (blockIdx.x == 0) {
             for (int32_t i = gridDim.x + tid; i < P.part_stride; i += B) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) P.part_out[c * P.part_stride + i] = 0.0;
+                for (int c = 0; c < NS; ++c) P.part_out[c * P.part_stride + i] = 0.0;
             }
         }
     }
-    block_sum4<B>(acc, s_red);
+    block_sumN<B, NS>(acc, s_red);
     if (tid == 0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) P.part_out[c * P.part_stride + blockIdx.x] = acc[c];
+        for (int c = 0; c < NS; ++c) P.part_out[c * P.part_stride + blockIdx.x] = acc[c];
     }
 }
 
-static size_t fused_lds_bytes(int32_t cap, int32_t B, bool dma)
+static size_t fused_lds_bytes(int32_t cap, int32_t B, bool dma, bool pre)
 {
-    return (size_t)cap * 32 + (size_t)(B / 64) * 32 + 16 + (dma ? (size_t)B * 96 : 0);
+    return (size_t)cap * 32 + (size_t)(B / 64) * (pre ? 48 : 32) + 16 + (dma ? (size_t)B * 96 : 0);
 }
 
 static bool fused_dma()
@@ -1338,32 +1389,46 @@ static bool fused_dma()
     return v != 0;
 }
 
-int fused_grid(int32_t B, int32_t cap, int32_t tiles, bool comm)
+// one table for the occupancy query and the launch: instantiation by (kernel family, B, write-through, COMM, PRE)
+typedef void (*fused_fn)(const FusedParams);
+template <int B, bool WT>
+static fused_fn fused_pick_dma(bool comm, bool pre)
+{
+    if (comm) return pre ? k_cg_fused_dma<B, WT, true, true> : k_cg_fused_dma<B, WT, true, false>;
+    return pre ? k_cg_fused_dma<B, WT, false, true> : k_cg_fused_dma<B, WT, false, false>;
+}
+template <int B>
+static fused_fn fused_pick_aos(bool comm, bool pre)
+{
+    // per-lane 48-byte-stride records: 16-byte write-through pieces measured slower than plain stores here
+    if (comm) return pre ? k_cg_fused<B, false, true, true> : k_cg_fused<B, false, true, false>;
+    return pre ? k_cg_fused<B, false, false, true> : k_cg_fused<B, false, false, false>;
+}
+static fused_fn fused_pick(int32_t B, bool dma, bool wt, bool comm, bool pre)
+{
+    if (dma) {
+        if (B == 256) return wt ? fused_pick_dma<256, true>(comm, pre) : fused_pick_dma<256, false>(comm, pre);
+        return wt ? fused_pick_dma<512, true>(comm, pre) : fused_pick_dma<512, false>(comm, pre);
+    }
+    if (B == 256) return fused_pick_aos<256>(comm, pre);
+    if (B == 1024) return fused_pick_aos<1024>(comm, pre);
+    return fused_pick_aos<512>(comm, pre);
+}
+
+int fused_grid(int32_t B, int32_t cap, int32_t tiles, bool comm, bool pre)
 {
     int dev = 0, cus = 256, per_cu = 1;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const bool dma = fused_dma() && B != 1024;
-    const size_t lds = fused_lds_bytes(cap, B, dma);
-    hipError_t e;
-#define MAG_OCC(K, BB)                                                                                                 \
-    e = comm ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, K<BB, false, true>, BB, lds)                      \
-             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, K<BB, false, false>, BB, lds)
-    if (dma) {
-        if (B == 256)
-            MAG_OCC(k_cg_fused_dma, 256);
-        else
-            MAG_OCC(k_cg_fused_dma, 512);
-    } else if (B == 256)
-        MAG_OCC(k_cg_fused, 256);
-    else if (B == 1024)
-        MAG_OCC(k_cg_fused, 1024);
-    else
-        MAG_OCC(k_cg_fused, 512);
-#undef MAG_OCC
+    const size_t lds = fused_lds_bytes(cap, B, dma, pre);
+    const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pick(B, dma, false, comm, pre),
+                                                                      B == 256 || B == 1024 ? B : 512, lds);
     if (e != hipSuccess || per_cu < 1) per_cu = 1;
     long g = (long)per_cu * cus;
     if (g > kMaxGrid) g = kMaxGrid;
+    if (const char *cap_env = getenv("MAG_TUNE_GRID")) // tests: few workgroups, so each walks several tiles
+        if (atoi(cap_env) > 0 && g > atoi(cap_env)) g = atoi(cap_env);
     if (g > tiles) g = tiles;
     return g < 1 ? 1 : (int)g;
 }
@@ -1371,34 +1436,10 @@ int fused_grid(int32_t B, int32_t cap, int32_t tiles, bool comm)
 void fused_launch(const FusedParams &P, int32_t B, int32_t grid, hipStream_t s)
 {
     const bool dma = fused_dma() && B != 1024;
-    const bool comm = P.comm_out_q != nullptr;
-    const size_t lds = fused_lds_bytes(P.cap, B, dma);
-#define MAG_FUSED(K, BB, WTV)                                                                                          \
-    do {                                                                                                               \
-        if (comm)                                                                                                      \
-            K<BB, WTV, true><<<grid, BB, lds, s>>>(P);                                                                 \
-        else                                                                                                           \
-            K<BB, WTV, false><<<grid, BB, lds, s>>>(P);                                                                \
-    } while (0)
-    if (dma) {
-        if (B == 256 && P.wt)
-            MAG_FUSED(k_cg_fused_dma, 256, true);
-        else if (B == 256)
-            MAG_FUSED(k_cg_fused_dma, 256, false);
-        else if (P.wt)
-            MAG_FUSED(k_cg_fused_dma, 512, true);
-        else
-            MAG_FUSED(k_cg_fused_dma, 512, false);
-        return;
-    }
-    // per-lane 48-byte-stride records: 16-byte write-through pieces measured slower than plain stores here
-    if (B == 256)
-        MAG_FUSED(k_cg_fused, 256, false);
-    else if (B == 1024)
-        MAG_FUSED(k_cg_fused, 1024, false);
-    else
-        MAG_FUSED(k_cg_fused, 512, false);
-#undef MAG_FUSED
+    const bool comm = P.comm_out_q != nullptr, pre = P.minvP != nullptr;
+    const int32_t threads = B == 256 || B == 1024 ? B : 512;
+    const size_t lds = fused_lds_bytes(P.cap, B, dma, pre);
+    fused_pick(B, dma, P.wt != 0, comm, pre)<<<grid, threads, lds, s>>>(P);
 }
 
 __global__ void __launch_bounds__(256) k_tile_meta(const int32_t *tile_deg, const int64_t *tile_off,
@@ -1423,11 +1464,11 @@ void tile_meta(const int32_t *tile_deg, const int64_t *tile_off, const int32_t *
 }
 
 template <int B>
-__global__ void __launch_bounds__(B) k_fused_init(const double2 *bP, Rqp *in, Rqp *out, int64_t N, int32_t T,
-                                                  int32_t t0, int32_t t1, double *part, int32_t stride)
+__global__ void __launch_bounds__(B) k_fused_init(const double2 *bP, const float4 *minvP, Rqp *in, Rqp *out, int64_t N,
+                                                  int32_t T, int32_t t0, int32_t t1, double *part, int32_t stride)
 {
     __shared__ double s_red[B / 64];
-    double acc = 0.0;
+    double acc = 0.0, rho = 0.0;
     const double2 z = make_double2(0.0, 0.0);
     for (int32_t t = blockIdx.x; t < T; t += gridDim.x) {
         const int64_t node = (int64_t)t * B + threadIdx.x;
@@ -1439,27 +1480,49 @@ __global__ void __launch_bounds__(B) k_fused_init(const double2 *bP, Rqp *in, Rq
             rec.p = z;
             in[node] = rec;
             out[node] = rec;
-            if (t >= t0 && t < t1) acc += b.x * b.x + b.y * b.y;
+            if (t >= t0 && t < t1) {
+                acc += b.x * b.x + b.y * b.y;
+                if (minvP) {
+                    const double2 zb = apply_minv(minvP[node], b);
+                    rho += b.x * zb.x + b.y * zb.y;
+                }
+            }
         }
     }
     const double tot = block_sum<B>(acc, s_red);
+    const double tot_rho = minvP ? block_sum<B>(rho, s_red) : 0.0;
     if (threadIdx.x == 0) {
         part[blockIdx.x] = tot;
         part[stride + blockIdx.x] = blockIdx.x == 0 ? 1.0 : 0.0; // "p.q" > 0: alpha finite, multiplies q = 0
-        part[2 * stride + blockIdx.x] = 0.0;
+        part[2 * stride + blockIdx.x] = tot_rho;                  // preconditioned: rho_0 = r0.Minv r0 (else r.q = 0)
         part[3 * stride + blockIdx.x] = 0.0;
+        if (minvP) part[4 * stride + blockIdx.x] = 0.0;
     }
 }
 
-void fused_init(const double2 *bP, Rqp *in, Rqp *out, int64_t N, int32_t B, int32_t T, int32_t t0, int32_t t1,
-                double *part, int32_t stride, int32_t grid, hipStream_t s)
+void fused_init(const double2 *bP, const float4 *minvP, Rqp *in, Rqp *out, int64_t N, int32_t B, int32_t T, int32_t t0,
+                int32_t t1, double *part, int32_t stride, int32_t grid, hipStream_t s)
 {
     if (B == 256)
-        k_fused_init<256><<<grid, 256, 0, s>>>(bP, in, out, N, T, t0, t1, part, stride);
+        k_fused_init<256><<<grid, 256, 0, s>>>(bP, minvP, in, out, N, T, t0, t1, part, stride);
     else if (B == 1024)
-        k_fused_init<1024><<<grid, 1024, 0, s>>>(bP, in, out, N, T, t0, t1, part, stride);
+        k_fused_init<1024><<<grid, 1024, 0, s>>>(bP, minvP, in, out, N, T, t0, t1, part, stride);
     else
-        k_fused_init<512><<<grid, 512, 0, s>>>(bP, in, out, N, T, t0, t1, part, stride);
+        k_fused_init<512><<<grid, 512, 0, s>>>(bP, minvP, in, out, N, T, t0, t1, part, stride);
+}
+
+// halo copies of the inverse node blocks, contiguous per tile like halo_xy
+__global__ void __launch_bounds__(256) k_halo_minv(const int32_t *halo_g, const float4 *minvP, int64_t halo_total,
+                                                   float4 *halo_minv)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < halo_total) halo_minv[i] = minvP[halo_g[i]];
+}
+
+void halo_minv(const int32_t *halo_g, const float4 *minvP, int64_t halo_total, float4 *out, hipStream_t s)
+{
+    if (halo_total > 0)
+        k_halo_minv<<<(unsigned)((halo_total + 255) / 256), 256, 0, s>>>(halo_g, minvP, halo_total, out);
 }
 
 __global__ void __launch_bounds__(256) k_fused_setup(const double *part, int nPart, int32_t stride, int stop_mode,

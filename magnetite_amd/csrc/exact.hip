@@ -218,6 +218,54 @@ void assemble_rows(const int32_t *brow, const int32_t *bcol, const int32_t *bptr
                                                         (const double2 *)xy, nu, youngs, thick, kval);
 }
 
+// Opt-in preconditioner (the reference has none, solver.rs:142): the node-diagonal 2x2 blocks of
+// K, summed over the incident elements in ascending element order with ke_block -- bitwise the diagonal blocks of
+// the assembled matrix, so the oracle can rebuild the same M from its own K -- then inverted on the free DOFs and
+// rounded to fp32 (oracle/magnetite_oracle.c:orc_block_jacobi, same operations).  One thread per node, Hilbert order.
+__global__ void __launch_bounds__(256) k_precond_blocks(const int32_t *inc_off, const uint32_t *inc, const uint32_t *perm,
+                                                        const int32_t *conn, const double2 *xy, const uint8_t *u_known,
+                                                        int64_t N, double nu, double youngs, double thick, int kind,
+                                                        float4 *minvP)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= N) return;
+    const int64_t i = perm[g];
+    double D[9];
+    stress_strain(nu, youngs, D);
+    double k00 = 0.0, k01 = 0.0, k11 = 0.0;
+    for (int32_t q = inc_off[g]; q < inc_off[g + 1]; ++q) {
+        const uint32_t v = inc[q];
+        const uint32_t e = v / 3u;
+        const int a = (int)(v - 3u * e);
+        const int32_t n0 = conn[3 * (int64_t)e], n1 = conn[3 * (int64_t)e + 1], n2 = conn[3 * (int64_t)e + 2];
+        double c00, c01, c10, c11;
+        ke_block(xy[n0], xy[n1], xy[n2], a, a, D, thick, c00, c01, c10, c11);
+        k00 += c00;
+        k01 += c01;
+        k11 += c11;
+    }
+    const bool fx = !u_known[2 * i], fy = !u_known[2 * i + 1];
+    double i00 = 0.0, i01 = 0.0, i11 = 0.0;
+    if (fx && fy && kind == 2) {
+        const double det = k00 * k11 - k01 * k01;
+        i00 = k11 / det;
+        i01 = (k01 / det) * -1.0;
+        i11 = k00 / det;
+    } else {
+        if (fx) i00 = 1.0 / k00;
+        if (fy) i11 = 1.0 / k11;
+    }
+    minvP[g] = make_float4((float)i00, (float)i01, (float)i11, 0.f);
+}
+
+void precond_blocks(const int32_t *inc_off, const uint32_t *inc, const uint32_t *perm, const int32_t *conn,
+                    const double *xy, const uint8_t *u_known, int64_t N, double nu, double youngs, double thick, int kind,
+                    float4 *minvP, hipStream_t s)
+{
+    k_precond_blocks<<<blocks_for(N, 256), 256, 0, s>>>(inc_off, inc, perm, conn, (const double2 *)xy, u_known, N, nu,
+                                                        youngs, thick, kind, minvP);
+}
+
 // solver.rs:365-404 + 427-432 on the CSR rows: known[r,k] = -(K[r,col]*u[col]) summed ascending, + f.
 __device__ inline double rhs_row(const int32_t *bptr, const int32_t *bcol, const double *kval, const uint8_t *u_known,
                                  const double *u_in, const double *f_in, int64_t r)

@@ -241,17 +241,26 @@ struct FusedParams {
     const int32_t *halo_qslot; // halo_total
     const double2 *comm_in_q;  // n_iface, all-reduced q of iterate j-1
     double2 *comm_out_q;       // n_iface, this rank's q of iterate j (zeros where it is not the owner)
+    // opt-in preconditioner (null = plain CG, the reference's iteration): inverse 2x2 node blocks (i00, i01, i11, 0)
+    // in fp32, Hilbert order, and their per-tile halo copies; the partial arrays are then five, not four
+    const float4 *minvP;
+    const float4 *halo_minv;
 };
 void tile_meta(const int32_t *tile_deg, const int64_t *tile_off, const int32_t *tile_hoff, int32_t T, TileMeta *meta,
                hipStream_t s);
 // workgroups of the fused kernel: all co-resident (occupancy query x CUs), so the launch is one persistent round --
 // measured best on MI355X (fewer, fatter workgroups also mean fewer dot partials for every workgroup to reduce)
-int fused_grid(int32_t B, int32_t cap, int32_t tiles, bool comm);
+int fused_grid(int32_t B, int32_t cap, int32_t tiles, bool comm, bool pre);
 void fused_launch(const FusedParams &P, int32_t B, int32_t grid, hipStream_t s);
 // in[node] = {-b, 0, 0}; part[0..] = {b.b partials over owned tiles, 1/grid, 0, 0} so that launch 0 gets
 // alpha finite, beta = 1
-void fused_init(const double2 *bP, Rqp *in, Rqp *out, int64_t N, int32_t B, int32_t T, int32_t t0, int32_t t1,
-                double *part, int32_t stride, int32_t grid, hipStream_t s);
+void fused_init(const double2 *bP, const float4 *minvP, Rqp *in, Rqp *out, int64_t N, int32_t B, int32_t T, int32_t t0,
+                int32_t t1, double *part, int32_t stride, int32_t grid, hipStream_t s);
+void halo_minv(const int32_t *halo_g, const float4 *minvP, int64_t halo_total, float4 *out, hipStream_t s);
+// exact.hip: inverse node-diagonal blocks of K_ff (kind 1: diagonal only, 2: 2x2 blocks), fp32, Hilbert order
+void precond_blocks(const int32_t *inc_off, const uint32_t *inc, const uint32_t *perm, const int32_t *conn,
+                    const double *xy, const uint8_t *u_known, int64_t N, double nu, double youngs, double thick, int kind,
+                    float4 *minvP, hipStream_t s);
 void fused_setup(const double *part, int32_t nPart, int32_t stride, int stop_mode, double tol, long long max_iter,
                  FusedState *st, hipStream_t s);
 // multi-GPU: slot tables of the exchange buffer [4 x g_all dot partials | q of the n_iface interface nodes]

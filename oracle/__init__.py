@@ -72,6 +72,8 @@ def lib():
                     C.c_int, C.c_double, C.c_int64, dp, dp, dp, C.POINTER(Stats), dp, C.c_int64]
         L.orc_run_dense.argtypes = run_args
         L.orc_run_sparse.argtypes = run_args
+        L.orc_run_sparse_pcg.argtypes = run_args + [C.c_int]
+        L.orc_block_jacobi.argtypes = [C.c_void_p, C.c_int64, bp, C.c_int, C.POINTER(C.c_float)]
         _lib = L
     return _lib
 
@@ -226,9 +228,18 @@ def stress(xy, conn, u, nu, youngs):
     return s[:E]
 
 
+def block_jacobi(K, N, u_known, kind):
+    """(i00, i01, i11) per node, fp32: the opt-in preconditioner's inverse node blocks (no reference counterpart)."""
+    out = np.zeros(3 * N + 1, dtype=np.float32)
+    lib().orc_block_jacobi(K._h, N, _b(np.ascontiguousarray(u_known, dtype=np.uint8)), int(kind),
+                           out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out[:3 * N].reshape(N, 3)
+
+
 def run(xy, conn, u_known, u_in, f_in, youngs, nu, thickness, path="sparse", stop_mode=STOP_RNORM,
-        tol=TARGET_CG_COST, max_iter=MAX_CG_ITER, hist_len=0):
-    """solver.rs:543-586 run(): returns dict(u, f, stress, iterations, final_cost, n_free, nnz_ff, history)."""
+        tol=TARGET_CG_COST, max_iter=MAX_CG_ITER, hist_len=0, precond=0):
+    """solver.rs:543-586 run(): returns dict(u, f, stress, iterations, final_cost, n_free, nnz_ff, history).
+    precond != 0 (sparse path only): Jacobi (1) / block-Jacobi (2) preconditioned CG -- an addition, not the reference."""
     xy, conn = _prep(xy, conn)
     N, E = xy.size // 2, conn.size // 3
     u_known = np.ascontiguousarray(u_known, dtype=np.uint8).reshape(-1)
@@ -240,10 +251,14 @@ def run(xy, conn, u_known, u_in, f_in, youngs, nu, thickness, path="sparse", sto
     s = np.empty(max(E, 1))
     st = Stats()
     hist = np.zeros(max(hist_len, 1))
-    fn = lib().orc_run_dense if path == "dense" else lib().orc_run_sparse
-    rc = fn(N, E, _d(xy), _i(conn), _b(u_known), _d(u_in), _d(f_in), float(youngs), float(nu),
+    args = (N, E, _d(xy), _i(conn), _b(u_known), _d(u_in), _d(f_in), float(youngs), float(nu),
             float(thickness), stop_mode, float(tol), int(max_iter), _d(u), _d(f), _d(s), C.byref(st),
             _d(hist), hist_len)
+    if precond:
+        assert path == "sparse"
+        rc = lib().orc_run_sparse_pcg(*args, int(precond))
+    else:
+        rc = (lib().orc_run_dense if path == "dense" else lib().orc_run_sparse)(*args)
     if rc != 0:
         raise RuntimeError(f"oracle run failed rc={rc}")
     return dict(u=u, f=f, stress=s[:E], iterations=int(st.iterations), final_cost=st.final_cost,

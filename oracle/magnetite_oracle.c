@@ -335,6 +335,96 @@ int64_t orc_cg_parallel(const orc_csr *A, const double *b, int stop_mode, double
     return it;
 }
 
+/* ------------------------------------- opt-in preconditioning (no reference) --- */
+
+/* SURVEY 8f rank 4.  The reference runs plain CG (solver.rs:142-157); this is an ADDITION with no reference
+ * counterpart, off by default on the HIP path, restated here only so the HIP kernels have a checker.
+ * M = the 2x2 node-diagonal blocks of K_ff (kind 2, block-Jacobi) or its diagonal (kind 1, Jacobi).  The inverse
+ * blocks are computed in double, then ROUNDED TO FLOAT (the HIP path stores them in fp32: any fixed SPD M gives
+ * the same solution, and 16 bytes per node is cheaper to stream than 32).  minv holds (i00, i01, i11) per node;
+ * a prescribed DOF drops out of its block (its residual is identically 0). */
+void orc_block_jacobi(const orc_csr *K, int64_t N, const uint8_t *u_known, int kind, float *minv)
+{
+    for (int64_t i = 0; i < N; ++i) {
+        double k00 = 0.0, k01 = 0.0, k11 = 0.0;
+        for (int64_t p = K->rowptr[2 * i]; p < K->rowptr[2 * i + 1]; ++p) {
+            if (K->col[p] == 2 * i) k00 = K->val[p];
+            if (K->col[p] == 2 * i + 1) k01 = K->val[p];
+        }
+        for (int64_t p = K->rowptr[2 * i + 1]; p < K->rowptr[2 * i + 2]; ++p)
+            if (K->col[p] == 2 * i + 1) k11 = K->val[p];
+        const int fx = !u_known[2 * i], fy = !u_known[2 * i + 1];
+        double i00 = 0.0, i01 = 0.0, i11 = 0.0;
+        if (fx && fy && kind == 2) {
+            const double det = k00 * k11 - k01 * k01;
+            i00 = k11 / det;
+            i01 = (k01 / det) * -1.0;
+            i11 = k00 / det;
+        } else {
+            if (fx) i00 = 1.0 / k00;
+            if (fy) i11 = 1.0 / k11;
+        }
+        minv[3 * i] = (float)i00;
+        minv[3 * i + 1] = (float)i01;
+        minv[3 * i + 2] = (float)i11;
+    }
+}
+
+/* Preconditioned CG in argmin's sign convention (r = A x - b, p = -z + beta p), textbook recurrences:
+ * alpha = r.z / p.Ap, beta = r'.z' / r.z.  Stop rule, cost (the TRUE residual norm, not the M-norm), best-iterate
+ * and b == 0 handling as orc_cg.  ms/mc/partner describe z = M^-1 r in the reduced numbering:
+ * z[f] = ms[f] * r[f] + (partner[f] >= 0 ? mc[f] * r[partner[f]] : 0). */
+int64_t orc_pcg(const orc_csr *A, const double *b, const double *ms, const double *mc, const int64_t *partner,
+                int stop_mode, double tol, int64_t max_iter, double *x_best, double *final_cost, double *history,
+                int64_t hist_len)
+{
+    const int64_t n = A->n;
+    double *x = (double *)calloc((size_t)n + 1, sizeof(double));
+    double *r = (double *)malloc(sizeof(double) * ((size_t)n + 1));
+    double *z = (double *)malloc(sizeof(double) * ((size_t)n + 1));
+    double *p = (double *)malloc(sizeof(double) * ((size_t)n + 1));
+    double *q = (double *)malloc(sizeof(double) * ((size_t)n + 1));
+    for (int64_t i = 0; i < n; ++i) r[i] = b[i] * -1.0;
+    for (int64_t i = 0; i < n; ++i) {
+        z[i] = ms[i] * r[i] + (partner[i] >= 0 ? mc[i] * r[partner[i]] : 0.0);
+        p[i] = z[i] * -1.0;
+    }
+    double rho = vdot(r, z, n);
+    const double rtr0 = vdot(r, r, n);
+    double target = tol;
+    if (stop_mode == ORC_STOP_REL) target = tol * sqrt(vdot(b, b, n));
+    double best = INFINITY;
+    if (rtr0 == 0.0) best = 0.0;
+    memcpy(x_best, x, sizeof(double) * (size_t)n);
+    int64_t it = 0;
+    while (it < max_iter && !(best <= target)) {
+        orc_spmv(A, p, q);
+        const double alpha = rho / vdot(p, q, n);
+        for (int64_t i = 0; i < n; ++i) x[i] = x[i] + alpha * p[i];
+        for (int64_t i = 0; i < n; ++i) r[i] = r[i] + alpha * q[i];
+        for (int64_t i = 0; i < n; ++i) z[i] = ms[i] * r[i] + (partner[i] >= 0 ? mc[i] * r[partner[i]] : 0.0);
+        const double rho_n = vdot(r, z, n);
+        const double beta = rho_n / rho;
+        rho = rho_n;
+        for (int64_t i = 0; i < n; ++i) p[i] = z[i] * -1.0 + beta * p[i];
+        const double rtr = vdot(r, r, n);
+        const double cost = (stop_mode == ORC_STOP_RNORM_SQ) ? fabs(rtr) : sqrt(rtr);
+        if (history && it < hist_len) history[it] = cost;
+        ++it;
+        if (cost < best) {
+            best = cost;
+            memcpy(x_best, x, sizeof(double) * (size_t)n);
+        }
+    }
+    if (final_cost) *final_cost = best;
+    free(x);
+    free(r);
+    free(z);
+    free(p);
+    free(q);
+    return it;
+}
+
 /* --------------------------------------------------------- post-solve --- */
 
 /* solver.rs:496-535  compute_stress: sigma = (D*B)*u_e, scalar =
@@ -545,11 +635,11 @@ orc_csr *orc_reduce_system(const orc_csr *K, const uint8_t *u_known, const doubl
 
 /* run() on the sparse restatement.  cg_iter_cap > 0 stops CG after that many
  * iterations regardless of cost (bench.py's bounded cpu_baseline sample). */
-int orc_run_sparse(int64_t N, int64_t E, const double *xy, const int32_t *conn,
-                   const uint8_t *u_known, const double *u_in, const double *f_in, double youngs,
-                   double nu, double thickness, int stop_mode, double tol, int64_t max_iter,
-                   double *u_out, double *f_out, double *stress_out, orc_stats *st,
-                   double *history, int64_t hist_len)
+static int run_sparse_impl(int64_t N, int64_t E, const double *xy, const int32_t *conn,
+                           const uint8_t *u_known, const double *u_in, const double *f_in, double youngs,
+                           double nu, double thickness, int stop_mode, double tol, int64_t max_iter,
+                           double *u_out, double *f_out, double *stress_out, orc_stats *st,
+                           double *history, int64_t hist_len, int precond)
 {
     const int64_t n = 2 * N;
     orc_csr *K = orc_assemble_sparse(N, E, xy, conn, nu, youngs, thickness);
@@ -559,7 +649,37 @@ int orc_run_sparse(int64_t N, int64_t E, const double *xy, const int32_t *conn,
     orc_csr *A = orc_reduce_system(K, u_known, u_in, f_in, b);
     double *xs = (double *)calloc((size_t)nf + 1, sizeof(double));
     double cost = 0.0;
-    const int64_t it = orc_cg(A, b, stop_mode, tol, max_iter, xs, &cost, history, hist_len);
+    int64_t it;
+    if (precond == 0) {
+        it = orc_cg(A, b, stop_mode, tol, max_iter, xs, &cost, history, hist_len);
+    } else {
+        float *minv = (float *)malloc(sizeof(float) * 3 * (size_t)N + 4);
+        orc_block_jacobi(K, N, u_known, precond, minv);
+        double *ms = (double *)calloc((size_t)nf + 1, sizeof(double));
+        double *mc = (double *)calloc((size_t)nf + 1, sizeof(double));
+        int64_t *partner = (int64_t *)malloc(sizeof(int64_t) * ((size_t)nf + 1));
+        int64_t f = 0;
+        for (int64_t i = 0; i < N; ++i) {
+            const int fx = !u_known[2 * i], fy = !u_known[2 * i + 1];
+            if (fx) {
+                ms[f] = (double)minv[3 * i];
+                mc[f] = (double)minv[3 * i + 1];
+                partner[f] = fy ? f + 1 : -1;
+                ++f;
+            }
+            if (fy) {
+                ms[f] = (double)minv[3 * i + 2];
+                mc[f] = (double)minv[3 * i + 1];
+                partner[f] = fx ? f - 1 : -1;
+                ++f;
+            }
+        }
+        it = orc_pcg(A, b, ms, mc, partner, stop_mode, tol, max_iter, xs, &cost, history, hist_len);
+        free(minv);
+        free(ms);
+        free(mc);
+        free(partner);
+    }
     if (st) {
         st->iterations = it;
         st->final_cost = cost;
@@ -583,4 +703,25 @@ int orc_run_sparse(int64_t N, int64_t E, const double *xy, const int32_t *conn,
     orc_csr_free(K);
     orc_stress(E, xy, conn, u_out, nu, youngs, stress_out);
     return 0;
+}
+
+int orc_run_sparse(int64_t N, int64_t E, const double *xy, const int32_t *conn,
+                   const uint8_t *u_known, const double *u_in, const double *f_in, double youngs,
+                   double nu, double thickness, int stop_mode, double tol, int64_t max_iter,
+                   double *u_out, double *f_out, double *stress_out, orc_stats *st,
+                   double *history, int64_t hist_len)
+{
+    return run_sparse_impl(N, E, xy, conn, u_known, u_in, f_in, youngs, nu, thickness, stop_mode, tol, max_iter,
+                           u_out, f_out, stress_out, st, history, hist_len, 0);
+}
+
+/* precond: 1 Jacobi, 2 block-Jacobi (orc_block_jacobi); everything else as orc_run_sparse */
+int orc_run_sparse_pcg(int64_t N, int64_t E, const double *xy, const int32_t *conn,
+                       const uint8_t *u_known, const double *u_in, const double *f_in, double youngs,
+                       double nu, double thickness, int stop_mode, double tol, int64_t max_iter,
+                       double *u_out, double *f_out, double *stress_out, orc_stats *st,
+                       double *history, int64_t hist_len, int precond)
+{
+    return run_sparse_impl(N, E, xy, conn, u_known, u_in, f_in, youngs, nu, thickness, stop_mode, tol, max_iter,
+                           u_out, f_out, stress_out, st, history, hist_len, precond);
 }

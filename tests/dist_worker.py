@@ -2,7 +2,7 @@
 
 mode callback : every rank drives the SAME GPU 0 through its own mag_ctx; the per-iteration all-reduces go through
                 the library's host-callback transport -> gloo.  Exercises the whole distributed CG path (tile-range
-                partition, interface list, pack / all-reduce / unpack, ghost-p recurrence, solution assembly) except
+                partition, interface list, exchange buffer, ghost recurrences, solution assembly) except
                 the RCCL call itself, which needs one GPU per rank.
 mode rccl1    : single rank, RCCL communicator of size 1, distributed protocol forced (MAG_TUNE_FORCE_DIST=1):
                 exercises dlopen(librccl), ncclCommInitRank, ncclAllReduce on the library's stream.
@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--mesh", type=int, default=96)
     ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--tile", type=int, default=256)
+    ap.add_argument("--precond", type=int, default=0, help="mag_options.preconditioner (checked against the oracle's PCG)")
     ap.add_argument("--stacked", type=int, default=0, help="bench.py's weak-scaling geometry: plate-with-hole stacked N times")
     a = ap.parse_args()
     import torch
@@ -42,7 +43,7 @@ def main():
     if a.mode == "rccl1":
         os.environ["MAG_TUNE_FORCE_DIST"] = "1"
         dist.init_process_group("gloo", rank=0, world_size=1, init_method="tcp://127.0.0.1:29533")
-        with Context(device=0, tile_nodes=a.tile, cg_variant=a.variant) as c:
+        with Context(device=0, tile_nodes=a.tile, cg_variant=a.variant, preconditioner=a.precond) as c:
             c.init_rccl_from_torch(dist, 0, 1)
             out = c.solve(prob)
     else:
@@ -52,14 +53,14 @@ def main():
             t = torch.from_numpy(arr)
             dist.all_reduce(t)
 
-        with Context(device=0, tile_nodes=a.tile, cg_variant=a.variant) as c:
+        with Context(device=0, tile_nodes=a.tile, cg_variant=a.variant, preconditioner=a.precond) as c:
             c.init_callback(allreduce, rank, world)
             out = c.solve(prob)
     ref = oracle.run(prob.xy_flat, prob.conn_flat, prob.u_known, prob.u_in, prob.f_in, prob.youngs_modulus,
-                     prob.poisson_ratio, prob.part_thickness, path="sparse")
+                     prob.poisson_ratio, prob.part_thickness, path="sparse", precond=a.precond)
     err = np.linalg.norm(out["u"] - ref["u"]) / np.linalg.norm(ref["u"])
     os.environ.pop("MAG_TUNE_FORCE_DIST", None)
-    with Context(device=0, tile_nodes=a.tile, cg_variant=a.variant) as c1:
+    with Context(device=0, tile_nodes=a.tile, cg_variant=a.variant, preconditioner=a.precond) as c1:
         single = c1.solve(prob)
     err1 = np.linalg.norm(out["u"] - single["u"]) / np.linalg.norm(single["u"])
     print(f"rank {rank}/{world} mode={a.mode} iters={out['iterations']} (single {single['iterations']}, oracle "

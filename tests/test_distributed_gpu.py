@@ -10,11 +10,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
-def launch(nproc, mode, port, variant=1, extra=()):
+def launch(nproc, mode, port, variant=1, extra=(), env_extra=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER, "--mode", mode, "--variant", str(variant),
            *extra]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env_extra or {}))
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
 
 
@@ -28,6 +28,18 @@ def test_four_ranks_on_the_weak_scaling_geometry(built):
     """bench.py --gpus 4's mesh (plate-with-hole stacked 4x along y) at reduced resolution, default tile size,
     default CG variant: 4 ranks share the one GPU, collectives through gloo."""
     r = launch(4, "callback", 29571, 1, ("--tile", "512", "--stacked", "4", "--mesh", "150"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_two_ranks_several_tiles_per_workgroup(built):
+    """MAG_TUNE_GRID=4: every workgroup of the COMM kernel walks several tiles, ghost loop strided over few workgroups"""
+    r = launch(2, "callback", 29576, 1, ("--precond", "2"), {"MAG_TUNE_GRID": "4"})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_three_ranks_with_the_opt_in_preconditioner(built):
+    """block-Jacobi PCG across ranks: five sums in the exchange buffer, ghost nodes apply Minv locally"""
+    r = launch(3, "callback", 29575, 1, ("--precond", "2"))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
 
 

@@ -4,11 +4,13 @@ Bars: bit-exact for integer/index work (CSR pattern, K_ff pattern, iteration boo
 reference-order fp64 kernels (K_e, assembled K, K_ff values, b: same operations in the same order, no FMA);
 <= 1e-8 relative L2 on nodal displacements (BASELINE.json north_star) for everything downstream of CG.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
 import oracle
-from magnetite_amd import Context, MagnetiteError, meshgen
+from magnetite_amd import Context, MagnetiteError, _lib, meshgen
 from magnetite_amd._lib import (MAG_ERR_BAD_ARGS, MAG_ERR_BC_MISMATCH, MAG_OP_CSR, MAG_STOP_REL,
                                 MAG_STOP_RNORM_SQ)
 
@@ -531,3 +533,79 @@ def test_fused_beta_expansion_tracks_the_exact_recurrence(built):
     assert np.allclose(hist[1][:50], hist[0][:50], rtol=1e-10)
     assert np.allclose(hist[1], hist[0], rtol=1e-6)
     assert np.allclose(hist[1][:50], href[:50], rtol=1e-10) and np.allclose(hist[1], href, rtol=1e-6)
+
+
+# ---- opt-in preconditioner: no reference counterpart, checked against the oracle's own PCG ----
+@pytest.mark.parametrize("kind", [1, 2], ids=["jacobi", "block-jacobi"])
+@pytest.mark.parametrize("tile", [256, 512])
+def test_preconditioned_cg_matches_oracle_pcg(built, kind, tile):
+    m = meshgen.perturb(meshgen.shuffle(meshgen.plate_with_holes(72, 60, 1.2, 1.0), 7), 0.2, 2)
+    p = meshgen.config_fixed_left_point_load(m)
+    a = dict(xy=p.xy_flat, conn=p.conn_flat, u_known=p.u_known, u_in=p.u_in, f_in=p.f_in, youngs=p.youngs_modulus,
+             nu=p.poisson_ratio, thickness=p.part_thickness)
+    n = 15
+    plain = oracle.run(**a, stop_mode=oracle.STOP_REL, tol=1e-10)
+    ref = oracle.run(**a, stop_mode=oracle.STOP_REL, tol=1e-10, precond=kind, hist_len=n)
+    with Context(device=0, tile_nodes=tile, preconditioner=kind, stop_mode=_lib.MAG_STOP_REL, tol=1e-10,
+                 history_len=n) as c:
+        out = c.solve(p)
+        hist = c.history(n)
+        st = c.stats()
+    assert st["converged"] == 1
+    # same M (fp32 inverse blocks built with the same operations) and the same recurrences -> the residual history
+    # starts on top of the oracle's.  Only the start is comparable: on this distorted mesh the true-residual history
+    # of ANY two summation orders (numpy vs C, same textbook PCG) differs by O(1) after ~40 iterations.
+    assert np.allclose(hist[:n], ref["history"][:n], rtol=1e-9), np.max(np.abs(hist[:n] / ref["history"][:n] - 1))
+    assert abs(out["iterations"] - ref["iterations"]) <= max(5, ref["iterations"] // 20)
+    assert out["iterations"] < 0.96 * plain["iterations"]         # the point of it on a distorted mesh (-7 % / -15 %)
+    for key in ("u", "f", "stress"):
+        scale = np.linalg.norm(plain[key])
+        assert np.linalg.norm(out[key] - ref[key]) <= 1e-8 * scale, key
+        assert np.linalg.norm(out[key] - plain[key]) <= 1e-7 * scale, key   # same solution as the reference's plain CG
+
+
+def test_preconditioner_default_off_and_rejected_where_unsupported(built):
+    o = _lib.Options()
+    _lib.lib().mag_default_options(C.byref(o))
+    assert o.preconditioner == 0
+    p = meshgen.config_fixed_left_pull_right(meshgen.plate(24, 24))
+    for bad in (dict(cg_variant=0), dict(precision=1), dict(cg_operator=_lib.MAG_OP_CSR), dict(op_variant=1)):
+        with Context(device=0, preconditioner=2, **bad) as c:
+            with pytest.raises(MagnetiteError) as e:
+                c.solve(p)
+            assert "preconditioner" in str(e.value)
+
+
+def test_preconditioned_full_size_property(built):
+    """1M-triangle benchmark mesh (two tiles per workgroup): the preconditioned solve satisfies K_ff u_f = b to the
+    requested relative residual under the PLAIN operator (size-independent), and lands on plain CG's solution.  On
+    this uniform mesh Jacobi scaling cannot help -- the iteration count is allowed to be somewhat higher."""
+    p = meshgen.baseline_problem("hole1m")
+    free = p.u_known == 0
+    with Context(device=0, stop_mode=_lib.MAG_STOP_REL, tol=1e-8) as c:
+        base = c.solve(p)
+    with Context(device=0, stop_mode=_lib.MAG_STOP_REL, tol=1e-8, preconditioner=2) as c:
+        out = c.solve(p)
+        st = c.stats()
+        assert st["converged"] == 1
+        r = (c.apply_operator(out["u"]) - p.f_in)[free]
+        assert np.linalg.norm(r) <= 1.01e-8 * st["rhs_norm"] + 1e-12 * np.abs(p.f_in).max()
+    assert out["iterations"] <= 1.3 * base["iterations"]
+    assert rel(out["u"], base["u"]) <= 1e-6
+
+
+def test_multi_tile_loops_against_the_oracle(built, monkeypatch):
+    """MAG_TUNE_GRID caps the persistent grid so that every workgroup walks several tiles on a mesh the oracle
+    finishes in seconds (normally only the >= 1M-node meshes do, and those are checked by properties only)."""
+    monkeypatch.setenv("MAG_TUNE_GRID", "3")
+    p = meshgen.config_fixed_left_pull_right(meshgen.perturb(meshgen.shuffle(meshgen.plate_with_holes(80), 11), 0.2, 5))
+    a = dict(xy=p.xy_flat, conn=p.conn_flat, u_known=p.u_known, u_in=p.u_in, f_in=p.f_in, youngs=p.youngs_modulus,
+             nu=p.poisson_ratio, thickness=p.part_thickness)
+    for kind in (0, 2):
+        ref = oracle.run(**a, precond=kind)
+        for tile in (256, 512):
+            with Context(device=0, tile_nodes=tile, preconditioner=kind) as c:
+                out = c.solve(p)
+                assert c.stats()["num_tiles"] > 6
+            assert rel(out["u"], ref["u"]) <= TOL_U, (kind, tile)
+            assert abs(out["iterations"] - ref["iterations"]) <= max(5, ref["iterations"] // 20), (kind, tile)
