@@ -160,3 +160,58 @@ def test_tensile_example_physics(built):
     a = xy[g["conn"]]
     area = 0.5 * ((a[:, 1, 0] - a[:, 0, 0]) * (a[:, 2, 1] - a[:, 0, 1]) - (a[:, 2, 0] - a[:, 0, 0]) * (a[:, 1, 1] - a[:, 0, 1]))
     assert np.all(area < 0) and float(g["final_cost"]) <= 1e-4
+
+
+def test_oracle_pcg_is_textbook_pcg_with_fp32_node_blocks():
+    """The opt-in preconditioner has no reference counterpart; its checker (orc_pcg / orc_block_jacobi) is pinned
+    here against an independent numpy statement: M^-1 = fp32-rounded inverses of the 2x2 node blocks of K_ff."""
+    import scipy.sparse as sp
+
+    from magnetite_amd import meshgen
+    p = meshgen.config_fixed_left_pull_right(meshgen.perturb(meshgen.plate_with_holes(20, 24, 1.0, 1.2), 0.2, 3))
+    N = p.mesh.num_nodes
+    K = oracle.assemble_sparse(p.xy_flat, p.conn_flat, p.poisson_ratio, p.youngs_modulus, p.part_thickness)
+    Kd = sp.csr_matrix((K.val, K.col, K.rowptr), shape=(K.n, K.n)).toarray()
+    free = (p.u_known == 0)
+    for kind in (1, 2):
+        minv = oracle.block_jacobi(K, N, p.u_known, kind)
+        assert minv.dtype == np.float32
+        Minv = np.zeros((2 * N, 2 * N))
+        for i in range(N):
+            blk = Kd[2 * i:2 * i + 2, 2 * i:2 * i + 2].copy()
+            f = free[2 * i:2 * i + 2]
+            if kind == 1 or not f.all():
+                inv = np.diag([1.0 / blk[0, 0] if f[0] else 0.0, 1.0 / blk[1, 1] if f[1] else 0.0])
+            else:
+                inv = np.linalg.inv(blk)
+            assert np.allclose([inv[0, 0], inv[0, 1], inv[1, 1]], minv[i], rtol=1e-6, atol=0)
+            Minv[2 * i:2 * i + 2, 2 * i:2 * i + 2] = [[minv[i, 0], minv[i, 1]], [minv[i, 1], minv[i, 2]]]
+        A = Kd[np.ix_(free, free)]
+        b = (p.f_in - Kd @ np.where(free, 0.0, p.u_in))[free]
+        Mi = Minv[np.ix_(free, free)]
+        x = np.zeros_like(b)
+        r = -b
+        z = Mi @ r
+        d = -z
+        rho = r @ z
+        it = 0
+        while it < 10000:
+            q = A @ d
+            alpha = rho / (d @ q)
+            x += alpha * d
+            r += alpha * q
+            z = Mi @ r
+            rho_n = r @ z
+            d = -z + (rho_n / rho) * d
+            rho = rho_n
+            it += 1
+            if np.sqrt(r @ r) <= 1e-4:
+                break
+        ref = oracle.run(p.xy_flat, p.conn_flat, p.u_known, p.u_in, p.f_in, p.youngs_modulus, p.poisson_ratio,
+                         p.part_thickness, precond=kind)
+        plain = oracle.run(p.xy_flat, p.conn_flat, p.u_known, p.u_in, p.f_in, p.youngs_modulus, p.poisson_ratio,
+                           p.part_thickness)
+        assert abs(ref["iterations"] - it) <= 2
+        assert np.linalg.norm(ref["u"][free] - x) <= 1e-9 * np.linalg.norm(x)
+        assert np.linalg.norm(ref["u"] - plain["u"]) <= 1e-8 * np.linalg.norm(plain["u"])
+        assert ref["iterations"] < plain["iterations"]
