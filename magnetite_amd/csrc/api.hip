@@ -77,7 +77,7 @@ struct mag_ctx {
     int64_t ell_total = 0;
     DevBuf scratch, small; // rocPRIM temp; small = bbox partials, bbox, err flag
     DevBuf sK0, sK1, sV0, sV1;
-    DevBuf perm, iperm, xyP, maskP, deg, inc_off, inc, tile_deg, tile_cnt, tile_off, ell;
+    DevBuf perm, iperm, xyP, maskP, deg, inc_off, inc, tile_deg, tile_rdeg, tile_cnt, tile_off, ell;
     // tile-local numbering for the LDS-halo operator
     bool use_lds = false;
     int tune_wt = 1;       // two-launch variant: write-through (sc1) stores of p, q, x, r
@@ -359,8 +359,11 @@ int ensure_order(mag_ctx *ctx)
         magk::fill_ell16(ctx->inc_off.as<int32_t>(), ctx->inc.as<uint32_t>(), ctx->conn.as<int32_t>(),
                          ctx->iperm.as<int32_t>(), ctx->tile_deg.as<int32_t>(), ctx->tile_off.as<int64_t>(),
                          ctx->tile_hoff.as<int32_t>(), ctx->halo_g.as<int32_t>(), N, B, T, ctx->ell.as<uint32_t>(), s);
+        HIPCHK(ctx->tile_rdeg.reserve(4 * ((size_t)T + 1)));
+        magk::ring16(ctx->tile_deg.as<int32_t>(), ctx->tile_off.as<int64_t>(), B, T, ctx->ell.as<uint32_t>(),
+                     ctx->tile_rdeg.as<int32_t>(), s);
         HIPCHK(ctx->tmeta.reserve(sizeof(magk::TileMeta) * (size_t)T));
-        magk::tile_meta(ctx->tile_deg.as<int32_t>(), ctx->tile_off.as<int64_t>(), ctx->tile_hoff.as<int32_t>(), T,
+        magk::tile_meta(ctx->tile_rdeg.as<int32_t>(), ctx->tile_off.as<int64_t>(), ctx->tile_hoff.as<int32_t>(), T,
                         ctx->tmeta.as<magk::TileMeta>(), s);
     } else {
         HIPCHK(ctx->ell.reserve(8 * (size_t)(h_total > 0 ? h_total : 1)));
@@ -461,7 +464,7 @@ magk::OpParams op_params(mag_ctx *ctx)
     P.nPart = magk::cg_grid(ctx->T);
     P.xyP = ctx->xyP.as<double2>();
     P.maskP = ctx->maskP.as<uint8_t>();
-    P.tile_deg = ctx->tile_deg.as<int32_t>();
+    P.tile_deg = (ctx->use_lds ? ctx->tile_rdeg : ctx->tile_deg).as<int32_t>(); // LDS tables are in ring form
     P.tile_off = ctx->tile_off.as<int64_t>();
     if (ctx->use_lds) {
         P.ell16 = ctx->ell.as<uint32_t>();
@@ -1161,7 +1164,7 @@ void mag_destroy(mag_ctx *ctx)
         if (ctx->graph) (void)hipGraphExecDestroy(ctx->graph);
         DevBuf *bufs[] = {&ctx->xy, &ctx->conn, &ctx->uknown, &ctx->uin, &ctx->fin, &ctx->scratch, &ctx->small,
                           &ctx->sK0, &ctx->sK1, &ctx->sV0, &ctx->sV1, &ctx->perm, &ctx->iperm, &ctx->xyP,
-                          &ctx->maskP, &ctx->deg, &ctx->inc_off, &ctx->inc, &ctx->tile_deg, &ctx->tile_cnt,
+                          &ctx->maskP, &ctx->deg, &ctx->inc_off, &ctx->inc, &ctx->tile_deg, &ctx->tile_rdeg, &ctx->tile_cnt,
                           &ctx->tile_off, &ctx->ell, &ctx->hcnt, &ctx->hoffn, &ctx->hk0, &ctx->hk1, &ctx->halo_g, &ctx->halo_xy,
                           &ctx->tile_hcnt, &ctx->tile_hoff, &ctx->iface, &ctx->comm_pq, &ctx->comm_rr, &ctx->pk0, &ctx->pk1, &ctx->pv0, &ctx->pv1, &ctx->head,
                           &ctx->blk, &ctx->rowcnt, &ctx->seg_start, &ctx->bptr, &ctx->brow, &ctx->bcol, &ctx->kval, &ctx->ke,

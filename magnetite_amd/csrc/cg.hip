@@ -286,7 +286,26 @@ __global__ void __launch_bounds__(B) k_operator(const OpParams P)
 // Same operator on the tile-local table (fill_ell16): the tile's halo nodes are staged in LDS next to
 // its owned nodes, so the incident-element loop is LDS + ALU only and every global access of the launch
 // is issued up front.  Slot words of the first 8 incident elements are prefetched into registers.
-constexpr int kSlotRegs = 8;
+constexpr int kSlotRegs = 5; // ring words kept in registers: 10 entries, a closed fan of valence <= 9
+
+// One word of the ring table (symbolic.hip, k_ring16): two 16-bit entries -- tile-local id in bits 0-10, bit 15 = no
+// triangle between the previous entry and this one, 0xffff = end.  Every other consecutive pair (prev, cur) is the
+// triangle (a, prev, cur): one LDS gather per entry instead of two per triangle.
+template <class V2, class Tri>
+__device__ inline void ring_word(uint32_t ww, const V2 *s_xy, const V2 *s_p, V2 &pxy, V2 &pp, Tri &&tri)
+{
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const uint32_t e = half ? (ww >> 16) : (ww & 0xffffu);
+        if (e != 0xffffu) {
+            const uint32_t id = e & 0x7ffu;
+            const V2 cxy = s_xy[id], cp = s_p[id];
+            if (!(e & 0x8000u)) tri(pxy, pp, cxy, cp);
+            pxy = cxy;
+            pp = cp;
+        }
+    }
+}
 
 template <int B, bool CG, bool WT>
 __global__ void __launch_bounds__(B) k_operator_lds(const OpParams P)
@@ -442,20 +461,14 @@ __global__ void __launch_bounds__(B) k_operator_lds(const OpParams P)
         __syncthreads();
 
         double fx = 0.0, fy = 0.0;
+        {
+            double2 rxy = ca, rp = pa; // previous ring entry; the first entry of every fan carries the break bit
+            auto tri = [&](const double2 bxy, const double2 bp, const double2 cxy, const double2 cp) {
+                corner_force(ca, pa, bxy, bp, cxy, cp, c0, nu, h, fx, fy);
+            };
 #pragma unroll
-        for (int k = 0; k < kSlotRegs; ++k) {
-            const uint32_t ww = w[k];
-            if (ww != 0xffffffffu) {
-                const uint32_t lb = ww & 0xffffu, lc = ww >> 16;
-                corner_force(ca, pa, s_xy[lb], s_p[lb], s_xy[lc], s_p[lc], c0, nu, h, fx, fy);
-            }
-        }
-        for (int32_t k = kSlotRegs; k < deg; ++k) {
-            const uint32_t ww = ell[(int64_t)k * B];
-            if (ww != 0xffffffffu) {
-                const uint32_t lb = ww & 0xffffu, lc = ww >> 16;
-                corner_force(ca, pa, s_xy[lb], s_p[lb], s_xy[lc], s_p[lc], c0, nu, h, fx, fy);
-            }
+            for (int k = 0; k < kSlotRegs; ++k) ring_word(w[k], s_xy, s_p, rxy, rp, tri);
+            for (int32_t k = kSlotRegs; k < deg; ++k) ring_word(ell[(int64_t)k * B], s_xy, s_p, rxy, rp, tri);
         }
         if (valid) {
             if (CG || P.masked) {
@@ -1075,20 +1088,14 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
         __syncthreads();
 
         double fx = 0.0, fy = 0.0;
+        {
+            double2 rxy = ca, rp = pn; // previous ring entry; the first entry of every fan carries the break bit
+            auto tri = [&](const double2 bxy, const double2 bp, const double2 cxy, const double2 cp) {
+                corner_force(ca, pn, bxy, bp, cxy, cp, c0, nu, h, fx, fy);
+            };
 #pragma unroll
-        for (int k = 0; k < kSlotRegs; ++k) {
-            const uint32_t ww = w[k];
-            if (ww != 0xffffffffu) {
-                const uint32_t lb = ww & 0xffffu, lc = ww >> 16;
-                corner_force(ca, pn, s_xy[lb], s_p[lb], s_xy[lc], s_p[lc], c0, nu, h, fx, fy);
-            }
-        }
-        for (int32_t k = kSlotRegs; k < deg; ++k) {
-            const uint32_t ww = ell[(int64_t)k * B];
-            if (ww != 0xffffffffu) {
-                const uint32_t lb = ww & 0xffffu, lc = ww >> 16;
-                corner_force(ca, pn, s_xy[lb], s_p[lb], s_xy[lc], s_p[lc], c0, nu, h, fx, fy);
-            }
+            for (int k = 0; k < kSlotRegs; ++k) ring_word(w[k], s_xy, s_p, rxy, rp, tri);
+            for (int32_t k = kSlotRegs; k < deg; ++k) ring_word(ell[(int64_t)k * B], s_xy, s_p, rxy, rp, tri);
         }
         if (valid) {
             if (m & 1) fx = 0.0;
@@ -1296,20 +1303,14 @@ __global__ void __launch_bounds__(B, 4) k_cg_fused_dma(const FusedParams P)
         __syncthreads();
 
         double fx = 0.0, fy = 0.0;
+        {
+            double2 rxy = ca, rp = pn; // previous ring entry; the first entry of every fan carries the break bit
+            auto tri = [&](const double2 bxy, const double2 bp, const double2 cxy, const double2 cp) {
+                corner_force(ca, pn, bxy, bp, cxy, cp, c0, nu, h, fx, fy);
+            };
 #pragma unroll
-        for (int k = 0; k < kSlotRegs; ++k) {
-            const uint32_t ww = w[k];
-            if (ww != 0xffffffffu) {
-                const uint32_t lb = ww & 0xffffu, lc = ww >> 16;
-                corner_force(ca, pn, s_xy[lb], s_p[lb], s_xy[lc], s_p[lc], c0, nu, h, fx, fy);
-            }
-        }
-        for (int32_t k = kSlotRegs; k < deg; ++k) {
-            const uint32_t ww = ell[(int64_t)k * B];
-            if (ww != 0xffffffffu) {
-                const uint32_t lb = ww & 0xffffu, lc = ww >> 16;
-                corner_force(ca, pn, s_xy[lb], s_p[lb], s_xy[lc], s_p[lc], c0, nu, h, fx, fy);
-            }
+            for (int k = 0; k < kSlotRegs; ++k) ring_word(w[k], s_xy, s_p, rxy, rp, tri);
+            for (int32_t k = kSlotRegs; k < deg; ++k) ring_word(ell[(int64_t)k * B], s_xy, s_p, rxy, rp, tri);
         }
         if (m & 1) fx = 0.0;
         if (m & 2) fy = 0.0;
@@ -1722,20 +1723,14 @@ __global__ void __launch_bounds__(B) k_cg_fused32(const Fused32Params P)
         __syncthreads();
 
         float fx = 0.f, fy = 0.f;
+        {
+            float2 rxy = ca, rp = pn; // previous ring entry; the first entry of every fan carries the break bit
+            auto tri = [&](const float2 bxy, const float2 bp, const float2 cxy, const float2 cp) {
+                corner_force32(ca, pn, bxy, bp, cxy, cp, c0, nu, h, fx, fy);
+            };
 #pragma unroll
-        for (int k = 0; k < kSlotRegs; ++k) {
-            const uint32_t ww = w[k];
-            if (ww != 0xffffffffu) {
-                const uint32_t lb = ww & 0xffffu, lc = ww >> 16;
-                corner_force32(ca, pn, s_xy[lb], s_p[lb], s_xy[lc], s_p[lc], c0, nu, h, fx, fy);
-            }
-        }
-        for (int32_t k = kSlotRegs; k < deg; ++k) {
-            const uint32_t ww = ell[(int64_t)k * B];
-            if (ww != 0xffffffffu) {
-                const uint32_t lb = ww & 0xffffu, lc = ww >> 16;
-                corner_force32(ca, pn, s_xy[lb], s_p[lb], s_xy[lc], s_p[lc], c0, nu, h, fx, fy);
-            }
+            for (int k = 0; k < kSlotRegs; ++k) ring_word(w[k], s_xy, s_p, rxy, rp, tri);
+            for (int32_t k = kSlotRegs; k < deg; ++k) ring_word(ell[(int64_t)k * B], s_xy, s_p, rxy, rp, tri);
         }
         if (valid) {
             if (m & 1) fx = 0.f;

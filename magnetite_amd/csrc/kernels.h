@@ -246,6 +246,9 @@ struct FusedParams {
     const float4 *minvP;
     const float4 *halo_minv;
 };
+// rewrites the tile-local table of fill_ell16 into ring form in place (symbolic.hip, k_ring16)
+void ring16(const int32_t *tile_deg, const int64_t *tile_off, int32_t B, int32_t T, uint32_t *ell, int32_t *tile_rdeg,
+            hipStream_t s);
 void tile_meta(const int32_t *tile_deg, const int64_t *tile_off, const int32_t *tile_hoff, int32_t T, TileMeta *meta,
                hipStream_t s);
 // workgroups of the fused kernel: all co-resident (occupancy query x CUs), so the launch is one persistent round --

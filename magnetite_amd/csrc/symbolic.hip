@@ -359,6 +359,91 @@ void fill_ell16(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn
     k_fill_ell16<<<T, 256, 0, s>>>(inc_off, inc, conn, iperm, tile_deg, tile_off, tile_hoff, halo_g, N, B, ell);
 }
 
+// Ring form of the tile-local table.  fill_ell16 leaves one word (lb | lc << 16) per incident triangle (a, b, c);
+// around a node consecutive triangles share a neighbour, so the same information is a walk over the neighbours:
+// a row becomes a sequence of 16-bit ENTRIES -- tile-local id in bits 0-10, bit 15 = "no triangle between the previous
+// entry and this one" (first entry of a fan), 0xffff = end -- and every consecutive pair (prev, cur) without the break
+// bit is one triangle (a, prev, cur) in its original orientation.  A closed fan of d triangles takes d + 1 entries
+// instead of 2 d ids: half the table bytes per CG iteration and half the LDS gathers in the operator kernels.
+// Rewritten in place (entries <= 2 d, two per word); rows of more than kRingMaxDeg triangles just get the break bit
+// on every b (each triangle its own fan).  tile_rdeg[t] = words the longest row of tile t now uses.
+constexpr int kRingMaxDeg = 32;
+
+__global__ void __launch_bounds__(256) k_ring16(const int32_t *tile_deg, const int64_t *tile_off, int32_t B, uint32_t *ell,
+                                                int32_t *tile_rdeg)
+{
+    const int32_t t = blockIdx.x;
+    const int32_t td = tile_deg[t];
+    uint32_t *dst = ell + tile_off[t];
+    int32_t wmax = 0;
+    for (int l = threadIdx.x; l < B; l += 256) {
+        uint32_t *row = dst + l; // row[k * B], k < td
+        int d = 0;
+        while (d < td && row[(int64_t)d * B] != 0xffffffffu) ++d;
+        int words = 0;
+        if (d > kRingMaxDeg) {
+            for (int k = 0; k < d; ++k) row[(int64_t)k * B] |= 0x8000u;
+            words = d;
+        } else if (d > 0) {
+            uint32_t pr[kRingMaxDeg];
+            uint16_t out[2 * kRingMaxDeg];
+            for (int k = 0; k < d; ++k) pr[k] = row[(int64_t)k * B];
+            uint32_t used = 0;
+            int n = 0, remaining = d;
+            while (remaining > 0) {
+                // fan start: the lowest unused triangle whose b is nobody's c; a closed fan starts at its lowest triangle
+                int start = -1, first = -1;
+                for (int i = 0; i < d && start < 0; ++i) {
+                    if ((used >> i) & 1u) continue;
+                    if (first < 0) first = i;
+                    const uint32_t bi = pr[i] & 0xffffu;
+                    bool fed = false;
+                    for (int j = 0; j < d; ++j)
+                        if (j != i && !((used >> j) & 1u) && (pr[j] >> 16) == bi) {
+                            fed = true;
+                            break;
+                        }
+                    if (!fed) start = i;
+                }
+                if (start < 0) start = first;
+                out[n++] = (uint16_t)((pr[start] & 0xffffu) | 0x8000u);
+                uint32_t cur = pr[start] >> 16;
+                out[n++] = (uint16_t)cur;
+                used |= 1u << start;
+                --remaining;
+                for (;;) {
+                    int nx = -1;
+                    for (int i = 0; i < d; ++i)
+                        if (!((used >> i) & 1u) && (pr[i] & 0xffffu) == cur) {
+                            nx = i;
+                            break;
+                        }
+                    if (nx < 0) break;
+                    cur = pr[nx] >> 16;
+                    out[n++] = (uint16_t)cur;
+                    used |= 1u << nx;
+                    --remaining;
+                }
+            }
+            words = (n + 1) / 2;
+            for (int k = 0; k < words; ++k) {
+                const uint32_t lo = out[2 * k], hi = 2 * k + 1 < n ? out[2 * k + 1] : 0xffffu;
+                row[(int64_t)k * B] = lo | (hi << 16);
+            }
+            for (int k = words; k < d; ++k) row[(int64_t)k * B] = 0xffffffffu;
+        }
+        wmax = words > wmax ? words : wmax;
+    }
+    if (wmax > 0) atomicMax(&tile_rdeg[t], wmax);
+}
+
+void ring16(const int32_t *tile_deg, const int64_t *tile_off, int32_t B, int32_t T, uint32_t *ell, int32_t *tile_rdeg,
+            hipStream_t s)
+{
+    (void)hipMemsetAsync(tile_rdeg, 0, 4 * (size_t)T, s);
+    k_ring16<<<T, 256, 0, s>>>(tile_deg, tile_off, B, ell, tile_rdeg);
+}
+
 // --------------------------------------------------------- CSR pattern ---
 __global__ void __launch_bounds__(256) k_csr_pairs(const int32_t *conn, int64_t n9, uint64_t *keys, uint32_t *vals)
 {

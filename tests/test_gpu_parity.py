@@ -609,3 +609,47 @@ def test_multi_tile_loops_against_the_oracle(built, monkeypatch):
                 assert c.stats()["num_tiles"] > 6
             assert rel(out["u"], ref["u"]) <= TOL_U, (kind, tile)
             assert abs(out["iterations"] - ref["iterations"]) <= max(5, ref["iterations"] // 20), (kind, tile)
+
+
+def test_ring_table_on_irregular_node_stars(built):
+    """The tile-local table stores every node's incident triangles as a walk over its neighbours (k_ring16).
+    Operator parity on node stars that are not a single closed fan: open boundary fans, two fans meeting in one
+    node (bow-tie), an edge shared by three triangles (non-manifold), mixed CCW / CW orientation, shuffled element
+    order, and a 40-fan (ring longer than the register-resident words, built by the > 32 fallback)."""
+    rng = np.random.default_rng(5)
+    base = meshgen.plate(6, 5)
+    xy = [tuple(v) for v in base.xy]
+    tri = [list(t) for t in base.conn]
+
+    def add(pt):
+        xy.append(pt)
+        return len(xy) - 1
+
+    # bow-tie: a second, separate fan hanging off node 0 (corner of the plate), not edge-connected to the first
+    a, b = add((-0.3, -0.1)), add((-0.1, -0.3))
+    tri.append([0, a, b])
+    # non-manifold edge: a third triangle on an interior edge of the plate
+    e0, e1 = tri[7][0], tri[7][1]
+    c = add((0.5 * (xy[e0][0] + xy[e1][0]) + 0.01, 0.5 * (xy[e0][1] + xy[e1][1]) + 0.013))
+    tri.append([e0, e1, c])
+    # 40-fan around a new hub, attached to the plate through one node
+    hub = add((2.0, 2.0))
+    ring = [add((2.0 + 0.4 * np.cos(t), 2.0 + 0.4 * np.sin(t))) for t in np.linspace(0, 2 * np.pi, 40, endpoint=False)]
+    for k in range(40):
+        tri.append([hub, ring[k], ring[(k + 1) % 40]])
+    tri.append([base.num_nodes - 1, ring[25], ring[24]])
+    tri = np.array(tri, dtype=np.int32)
+    flip = rng.random(len(tri)) < 0.3                      # mixed orientation: CW elements get negative stiffness
+    tri[flip] = tri[flip][:, ::-1]
+    tri = tri[rng.permutation(len(tri))]
+    m = meshgen.Mesh(np.array(xy, dtype=np.float64), np.ascontiguousarray(tri), "zoo")
+    p = meshgen.apply_boundary_rules(m, [meshgen.BoundaryRule("hold", x_max=1e-9, ux=0.0, uy=0.0)])
+    K = oracle.assemble_sparse(p.xy_flat, p.conn_flat, p.poisson_ratio, p.youngs_modulus, p.part_thickness)
+    x = rng.standard_normal(2 * m.num_nodes)
+    want = K.spmv(x)
+    for tile in (256, 512):
+        for variant in (0, 1):
+            with Context(device=0, tile_nodes=tile, op_variant=variant) as c:
+                c.upload_problem(p)
+                got = c.apply_operator(x, masked=False)
+            assert rel(got, want) < 1e-12, (tile, variant)
