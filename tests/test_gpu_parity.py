@@ -653,3 +653,23 @@ def test_ring_table_on_irregular_node_stars(built):
                 c.upload_problem(p)
                 got = c.apply_operator(x, masked=False)
             assert rel(got, want) < 1e-12, (tile, variant)
+
+
+@pytest.mark.parametrize("variant", [1, 0])
+def test_degenerate_element_is_reported_not_hung(built, variant):
+    """A zero-area triangle makes B (solver.rs:204-230: division by 2A) and hence K non-finite; the reference would
+    feed NaNs to argmin.  The library must end the solve within a few launches and say so (MAG_ERR_NOT_CONVERGED,
+    stats.breakdown), never spin to max_iter or fault."""
+    m = meshgen.plate(8, 8)
+    xy = m.xy.copy()
+    conn = m.conn.copy()
+    a, b, _ = conn[10]
+    xy = np.vstack([xy, 0.5 * (xy[a] + xy[b])])             # a node exactly on an existing edge ...
+    conn = np.vstack([conn, [a, b, len(xy) - 1]])            # ... and a triangle of area 0 on it
+    p = meshgen.config_fixed_left_pull_right(meshgen.Mesh(xy, np.ascontiguousarray(conn, dtype=np.int32), "degenerate"))
+    with Context(device=0, cg_variant=variant) as c:
+        with pytest.raises(MagnetiteError) as e:
+            c.solve(p)
+        st = c.stats()
+    assert "non-finite" in str(e.value)
+    assert st["breakdown"] == 1 and st["converged"] == 0 and st["iterations"] <= 3
