@@ -42,6 +42,10 @@ struct DevBuf {
         p = nullptr;
         cap = 0;
     }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); } // every buffer of a mag_ctx goes with it (mag_destroy selects the device first)
     template <class T>
     T *as() const { return (T *)p; }
 };
@@ -400,7 +404,8 @@ int csr_symbolic(mag_ctx *ctx)
     HIPCHK(hipMemcpyAsync(&h_last[1], ctx->head.as<int32_t>() + (n9 - 1), 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const int64_t nb = (int64_t)h_last[0] + h_last[1];
-    if (4 * nb >= (int64_t(1) << 31)) return fail(ctx, MAG_ERR_TOO_LARGE, "nnz of K (%lld) exceeds int32", (long long)(4 * nb));
+    if (4 * nb >= (int64_t(1) << 31))
+        return fail(ctx, MAG_ERR_TOO_LARGE, "nnz of K (%lld) exceeds int32", (long long)(4 * nb));
     ctx->nb = nb;
     HIPCHK(ctx->seg_start.reserve(4 * ((size_t)nb + 1)));
     HIPCHK(ctx->brow.reserve(4 * (size_t)nb));
@@ -632,7 +637,8 @@ int cg_phase(mag_ctx *ctx)
         magk::iface_pack(ctx->partRR.as<double>(), magk::cg_grid(ctx->T), nullptr, nullptr, 0, 0, 0,
                          ctx->comm_rr.as<double>(), s);
         std::string msg;
-        if (int rc = ctx->comm.allreduce_sum(ctx->comm_rr.as<double>(), 1, s, msg)) return fail(ctx, rc, "%s", msg.c_str());
+        if (int rc = ctx->comm.allreduce_sum(ctx->comm_rr.as<double>(), 1, s, msg))
+            return fail(ctx, rc, "%s", msg.c_str());
         magk::cg_setup(ctx->comm_rr.as<double>(), 1, ctx->opt.stop_mode, ctx->opt.tol, (long long)ctx->opt.max_iter,
                        ctx->state.as<CgState>(), s);
     } else {
@@ -667,7 +673,8 @@ int cg_phase(mag_ctx *ctx)
         // assemble the full solution on every rank: each contributes its own nodes, zeros elsewhere
         magk::zero_unowned(ctx->x.as<double2>(), ctx->N, ctx->own0, ctx->own1, s);
         std::string msg;
-        if (int rc = ctx->comm.allreduce_sum(ctx->x.as<double>(), 2 * ctx->N, s, msg)) return fail(ctx, rc, "%s", msg.c_str());
+        if (int rc = ctx->comm.allreduce_sum(ctx->x.as<double>(), 2 * ctx->N, s, msg))
+            return fail(ctx, rc, "%s", msg.c_str());
     }
     HIPCHK(hipMemcpyAsync(&ctx->h_state[2], ctx->state.p, sizeof(CgState), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -883,7 +890,8 @@ int cg_phase_fused(mag_ctx *ctx)
     if (ctx->dist) {
         magk::zero_unowned(ctx->x.as<double2>(), ctx->N, ctx->own0, ctx->own1, s);
         std::string msg;
-        if (int rc = ctx->comm.allreduce_sum(ctx->x.as<double>(), 2 * ctx->N, s, msg)) return fail(ctx, rc, "%s", msg.c_str());
+        if (int rc = ctx->comm.allreduce_sum(ctx->x.as<double>(), 2 * ctx->N, s, msg))
+            return fail(ctx, rc, "%s", msg.c_str());
     }
     HIPCHK(hipMemcpyAsync(&ctx->h_fstate[2], ctx->fstate.p, sizeof(FusedState), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -1162,18 +1170,6 @@ void mag_destroy(mag_ctx *ctx)
         (void)hipStreamSynchronize(ctx->stream);
         ctx->comm.destroy();
         if (ctx->graph) (void)hipGraphExecDestroy(ctx->graph);
-        DevBuf *bufs[] = {&ctx->xy, &ctx->conn, &ctx->uknown, &ctx->uin, &ctx->fin, &ctx->scratch, &ctx->small,
-                          &ctx->sK0, &ctx->sK1, &ctx->sV0, &ctx->sV1, &ctx->perm, &ctx->iperm, &ctx->xyP,
-                          &ctx->maskP, &ctx->deg, &ctx->inc_off, &ctx->inc, &ctx->tile_deg, &ctx->tile_rdeg, &ctx->tile_cnt,
-                          &ctx->tile_off, &ctx->ell, &ctx->hcnt, &ctx->hoffn, &ctx->hk0, &ctx->hk1, &ctx->halo_g, &ctx->halo_xy,
-                          &ctx->tile_hcnt, &ctx->tile_hoff, &ctx->iface, &ctx->comm_pq, &ctx->comm_rr, &ctx->pk0, &ctx->pk1, &ctx->pv0, &ctx->pv1, &ctx->head,
-                          &ctx->blk, &ctx->rowcnt, &ctx->seg_start, &ctx->bptr, &ctx->brow, &ctx->bcol, &ctx->kval, &ctx->ke,
-                          &ctx->isfree, &ctx->fidx, &ctx->rcnt, &ctx->rowoff, &ctx->rp_ff, &ctx->col_ff,
-                          &ctx->val_ff, &ctx->b_ff, &ctx->rp_full, &ctx->col_full, &ctx->x, &ctx->r, &ctx->p0,
-                          &ctx->p1, &ctx->q, &ctx->bP, &ctx->tmpP, &ctx->partRR, &ctx->partPQ, &ctx->state,
-                          &ctx->hist, &ctx->u, &ctx->f, &ctx->stress, &ctx->rqp0, &ctx->rqp1, &ctx->fpart, &ctx->fstate,
-                          &ctx->tmeta, &ctx->comm_f, &ctx->own_qslot, &ctx->halo_qslot, &ctx->minvP, &ctx->halo_minv, &ctx->xy32, &ctx->hxy32, &ctx->rqp32a, &ctx->rqp32b, &ctx->x32};
-        for (DevBuf *b : bufs) b->release();
         if (ctx->h_state) (void)hipHostFree(ctx->h_state);
         if (ctx->h_fstate) (void)hipHostFree(ctx->h_fstate);
         for (int i = 0; i < 10; ++i)
@@ -1224,9 +1220,11 @@ int mag_upload(mag_ctx *ctx, const mag_problem *p)
     if (!p || !p->xy || !p->conn || !p->u_known || !p->u_in || !p->f_in)
         return fail(ctx, MAG_ERR_BAD_ARGS, "null problem pointer");
     const int64_t N = p->num_nodes, E = p->num_elements;
-    if (N < 1 || E < 1) return fail(ctx, MAG_ERR_BAD_ARGS, "empty mesh (nodes=%lld elements=%lld)", (long long)N, (long long)E);
+    if (N < 1 || E < 1)
+        return fail(ctx, MAG_ERR_BAD_ARGS, "empty mesh (nodes=%lld elements=%lld)", (long long)N, (long long)E);
     if (N >= (int64_t(1) << 30) || 9 * E >= (int64_t(1) << 31))
-        return fail(ctx, MAG_ERR_TOO_LARGE, "mesh too large for int32 indexing (nodes=%lld elements=%lld)", (long long)N, (long long)E);
+        return fail(ctx, MAG_ERR_TOO_LARGE, "mesh too large for int32 indexing (nodes=%lld elements=%lld)", (long long)N,
+                    (long long)E);
     if (!(p->poisson_ratio * p->poisson_ratio != 1.0))
         return fail(ctx, MAG_ERR_BAD_ARGS, "poisson_ratio^2 == 1");
     const hipMemcpyKind kind = p->memory == MAG_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -1348,7 +1346,9 @@ int mag_run(mag_ctx *ctx)
     st.lds_operator = ctx->use_lds ? 1 : 0;
     st.n_free = ctx->nf;
     ctx->have_run = true;
-    if (st.breakdown) return fail(ctx, MAG_ERR_NOT_CONVERGED, "Conjugate Gradient error: non-finite residual after %lld iterations", (long long)st.iterations);
+    if (st.breakdown)
+        return fail(ctx, MAG_ERR_NOT_CONVERGED, "Conjugate Gradient error: non-finite residual after %lld iterations",
+                    (long long)st.iterations);
     if (!st.converged)
         return fail(ctx, MAG_ERR_NOT_CONVERGED, "Conjugate Gradient did not reach cost %.3e in %lld iterations (cost %.3e)",
                     ctx->opt.tol, (long long)st.iterations, st.final_cost);
