@@ -1419,8 +1419,8 @@ static size_t fused_lds_bytes(int32_t cap, int32_t B, bool dma, bool pre)
 
 static bool fused_dma()
 {
-    static const int v = [] { const char *e = getenv("MAG_TUNE_DMA"); return e ? atoi(e) : 1; }();
-    return v != 0;
+    const char *e = getenv("MAG_TUNE_DMA"); // read per call: tests switch kernel families inside one process
+    return e ? atoi(e) != 0 : true;
 }
 
 // one table for the occupancy query and the launch: instantiation by (kernel family, B, write-through, COMM, PRE)
