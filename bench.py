@@ -93,7 +93,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cg-variant", type=int, default=1, help="1: one fused launch per CG iteration, 0: two launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-iters", type=int, default=150)
+    ap.add_argument("--cpu-sample-iters", type=int, default=1500,
+                    help="CG iterations of the 1-thread CPU sample (default ~11 s at 1M triangles; x4 for the OpenMP leg)")
     ap.add_argument("--op-reps", type=int, default=400)
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="world size 1 only: still create the nccl process group and the RCCL communicator and run "
