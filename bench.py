@@ -99,6 +99,9 @@ def main():
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="world size 1 only: still create the nccl process group and the RCCL communicator and run "
                          "the distributed CG protocol (iteration kernel + one in-place all-reduce every iteration)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="REHEARSAL of the N > 1 code path on a one-GPU box: every rank drives GPU 0 and the collectives "
+                         "go through gloo (host callback) instead of RCCL; the printed line is marked, it is no result")
     args = ap.parse_args()
 
     import torch  # first: libmagnetite_hip.so then shares torch's HIP runtime and RCCL (same SONAMEs)
@@ -113,6 +116,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the solver has no CPU path")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.rehearse_dist
     if args.rehearse_dist:
@@ -121,7 +126,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29577")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-    if use_dist:
+    if use_dist and args.share_gpu:
+        dist.init_process_group("gloo")
+    elif use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     stop_mode = {"rel": _lib.MAG_STOP_REL, "rnorm": _lib.MAG_STOP_RNORM, "rnorm_sq": _lib.MAG_STOP_RNORM_SQ}[args.stop]
@@ -130,7 +137,11 @@ def main():
 
     ctx = Context(device=local_rank, stop_mode=stop_mode, tol=args.tol, tile_nodes=args.tile,
                   check_every=args.check_every, use_graph=0 if args.no_graph else 1, cg_variant=args.cg_variant)
-    if use_dist:
+    if use_dist and args.share_gpu:
+        def host_allreduce(arr):
+            dist.all_reduce(torch.from_numpy(arr))
+        ctx.init_callback(host_allreduce, rank, world)
+    elif use_dist:
         ctx.init_rccl_from_torch(dist, rank, world)
     ctx.upload_problem(prob)  # inputs resident in HBM before the timed region
 
@@ -148,7 +159,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.share_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -214,6 +225,8 @@ def main():
             out["cpu_baseline"]["cores_available"] = os.cpu_count()
         else:
             out["cpu_baseline"] = None
+        if args.share_gpu:
+            out["rehearsal"] = "ranks share GPU 0, collectives through gloo: exercises the N > 1 code path, not a result"
         print(json.dumps(out), flush=True)
 
     ctx.close()

@@ -36,6 +36,24 @@ def test_bench_prints_one_contract_line(built):
     assert d["value"] > 10.0 * cb["value"]          # north_star: >= 10x the CPU solver at 1 GPU
 
 
+def test_bench_multi_rank_code_path_on_one_gpu(built):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed with both
+    ranks on the one GPU and gloo in place of RCCL (--share-gpu): stacked weak-scaling mesh, barriers, max-over-ranks
+    timing, rank 0 prints the single line."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29581", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu",
+           "--workload", "plate100k", "--steps", "1", "--warmup", "1", "--op-reps", "20"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None and "rehearsal" in d
+    assert d["config"]["parallelism"] == "strips2" and d["config"]["elements"] == 2 * 100352
+    assert d["cg_converged"] == 1 and d["value"] > 0
+
+
 def test_smoke_entry_point(built):
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, capture_output=True,
                        text=True, timeout=900)
