@@ -675,3 +675,31 @@ def test_degenerate_element_is_reported_not_hung(built, variant):
         st = c.stats()
     assert "non-finite" in str(e.value)
     assert st["breakdown"] == 1 and st["converged"] == 0 and st["iterations"] <= 3
+
+
+def test_repeated_solves_do_not_grow_device_memory(built):
+    """Buffers are grow-only and owned by the context: alternating problem sizes and option sets for 40 solves must
+    leave the free device memory where it was after the first round, and destroying the context returns it."""
+    L = _lib.lib()
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(), C.c_size_t()
+
+    def free_bytes():
+        assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
+
+    probs = [meshgen.config_fixed_left_pull_right(meshgen.plate_with_holes(n)) for n in (40, 64, 24)]
+    with Context(device=0) as warm:                      # runtime pools, code objects, rocPRIM state: allocated once
+        warm.solve(probs[1])
+    base = free_bytes()
+    c = Context(device=0)
+    for p in probs:
+        c.solve(p)
+    after_first = free_bytes()
+    for k in range(40):
+        c.options.history_len = 0
+        c.solve(probs[k % 3])
+    assert free_bytes() >= after_first - (1 << 20)
+    c.close()
+    assert free_bytes() >= base - (8 << 20)
+    assert L.mag_version() == 1
