@@ -1417,10 +1417,15 @@ static size_t fused_lds_bytes(int32_t cap, int32_t B, bool dma, bool pre)
     return (size_t)cap * 32 + (size_t)(B / 64) * (pre ? 48 : 32) + 16 + (dma ? (size_t)B * 96 : 0);
 }
 
-static bool fused_dma()
+static size_t fused_lds_bytes(int32_t cap, int32_t B, bool dma, bool pre);
+static bool fused_dma(int32_t B, int32_t cap, bool pre)
 {
     const char *e = getenv("MAG_TUNE_DMA"); // read per call: tests switch kernel families inside one process
-    return e ? atoi(e) != 0 : true;
+    if (e && atoi(e) == 0) return false;
+    // one 1024-node tile per CU: the stages need 96 KiB on top of the node images (measured at 1M triangles: 23.1 us
+    // per iteration against 32.3 us with per-lane records; 512-node tiles remain the faster choice at 19.1 us)
+    if (B == 1024) return fused_lds_bytes(cap, B, true, pre) <= 160 * 1024;
+    return true;
 }
 
 // one table for the occupancy query and the launch: instantiation by (kernel family, B, write-through, COMM, PRE)
@@ -1442,6 +1447,7 @@ static fused_fn fused_pick(int32_t B, bool dma, bool wt, bool comm, bool pre)
 {
     if (dma) {
         if (B == 256) return wt ? fused_pick_dma<256, true>(comm, pre) : fused_pick_dma<256, false>(comm, pre);
+        if (B == 1024) return wt ? fused_pick_dma<1024, true>(comm, pre) : fused_pick_dma<1024, false>(comm, pre);
         return wt ? fused_pick_dma<512, true>(comm, pre) : fused_pick_dma<512, false>(comm, pre);
     }
     if (B == 256) return fused_pick_aos<256>(comm, pre);
@@ -1454,7 +1460,7 @@ int fused_grid(int32_t B, int32_t cap, int32_t tiles, bool comm, bool pre)
     int dev = 0, cus = 256, per_cu = 1;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const bool dma = fused_dma() && B != 1024;
+    const bool dma = fused_dma(B, cap, pre);
     const size_t lds = fused_lds_bytes(cap, B, dma, pre);
     const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fused_pick(B, dma, false, comm, pre),
                                                                       B == 256 || B == 1024 ? B : 512, lds);
@@ -1469,8 +1475,8 @@ int fused_grid(int32_t B, int32_t cap, int32_t tiles, bool comm, bool pre)
 
 void fused_launch(const FusedParams &P, int32_t B, int32_t grid, hipStream_t s)
 {
-    const bool dma = fused_dma() && B != 1024;
     const bool comm = P.comm_out_q != nullptr, pre = P.minvP != nullptr;
+    const bool dma = fused_dma(B, P.cap, pre);
     const int32_t threads = B == 256 || B == 1024 ? B : 512;
     const size_t lds = fused_lds_bytes(P.cap, B, dma, pre);
     fused_pick(B, dma, P.wt != 0, comm, pre)<<<grid, threads, lds, s>>>(P);
