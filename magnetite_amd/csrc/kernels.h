@@ -132,7 +132,7 @@ struct OpParams {
     const int32_t *tile_deg;
     const int64_t *tile_off;
     const int2 *ell;         // gather variant: global (Hilbert) ids, halo read from global memory
-    const uint32_t *ell16;   // LDS-halo variant (nullptr => gather variant): tile-local ids lb | lc<<16
+    const uint32_t *ell16;   // LDS-halo variant (nullptr => gather variant): ring table of tile-local ids (k_ring16)
     const int32_t *tile_hoff; // T+1 offsets into halo_g
     const int32_t *halo_g;   // per tile: sorted Hilbert ids of its halo nodes
     const double2 *halo_xy;  // their coordinates, same layout (static copy)
