@@ -703,3 +703,28 @@ def test_repeated_solves_do_not_grow_device_memory(built):
     c.close()
     assert free_bytes() >= base - (8 << 20)
     assert L.mag_version() == 1
+
+
+def test_timing_hooks_report_plausible_launch_times(built):
+    """mag_time_operator / mag_time_spmv (the HIP-event figures bench.py turns into roofline fractions): they need a
+    completed run, return positive per-launch times, the whole-iteration kernel costs more than the plain SpMV and
+    neither is faster than the 8 TB/s HBM peak allows for the bytes it must move."""
+    p = meshgen.config_fixed_left_pull_right(meshgen.plate_with_holes(300))
+    with Context(device=0, stop_mode=MAG_STOP_REL, tol=1e-6) as c:
+        c.upload_problem(p)
+        with pytest.raises(MagnetiteError):
+            c.time_operator(10)
+        c.run()
+        us_it = c.time_operator(50) * 1e3
+        us_mv = c.time_spmv(50) * 1e3
+        u1 = c.download()[0]
+        c.run()                                  # the hooks run on scratch state: a later solve is unaffected
+        assert np.array_equal(c.download()[0], u1)
+    E, N = p.mesh.num_elements, p.mesh.num_nodes
+    assert us_it > us_mv > 0
+    assert (12 * E + 50 * N) / (us_mv * 1e-6) < 8e12 and 177 * N / (us_it * 1e-6) < 8e12
+    for variant in (0,):
+        with Context(device=0, cg_variant=variant, stop_mode=MAG_STOP_REL, tol=1e-6) as c:
+            c.upload_problem(p)
+            c.run()
+            assert c.time_operator(20) > 0
