@@ -91,7 +91,9 @@ def main():
     ap.add_argument("--tile", type=int, default=0, help="0: library default (512 for >= 262144 nodes, else 256)")
     ap.add_argument("--check-every", type=int, default=64)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--cg-variant", type=int, default=1, help="1: one fused launch per CG iteration, 0: two launches")
+    ap.add_argument("--cg-variant", type=int, default=2,
+                    help="2: on-chip single-launch CG when the mesh fits the chip (else as 1), 1: one fused launch per CG "
+                         "iteration, 0: two launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-iters", type=int, default=1500,
                     help="CG iterations of the 1-thread CPU sample (default ~11 s at 1M triangles; x4 for the OpenMP leg)")

@@ -89,10 +89,14 @@ typedef struct mag_options {
     int32_t verbose;      /* 1: print the reference's "info:" phase lines to stdout        */
     int32_t op_variant;   /* 0 (default): LDS-halo operator when every tile fits LDS, else the
                              global-gather operator; 1: always the global-gather operator  */
-    int32_t cg_variant;   /* 1 (default): one fused launch per CG iteration -- argmin's recurrences with the
-                             numerator of beta, |r_new|^2, expanded from exact dots of the previous iterate
-                             (r.r + 2 alpha r.q + alpha^2 q.q) so that one grid-wide reduction per iteration
-                             suffices; alpha, the stop test and the reported cost use the true r.r.
+    int32_t cg_variant;   /* One recurrence for 1 and 2 -- argmin's, with the numerator of beta, |r_new|^2, expanded
+                             from exact dots of the previous iterate (r.r + 2 alpha r.q + alpha^2 q.q) so that one
+                             grid-wide reduction per iteration suffices; alpha, the stop test and the reported
+                             cost use the true r.r.
+                             2 (default): on-chip -- when the whole mesh fits the registers and LDS of the chip
+                               (about 0.5M nodes) the entire solve is ONE launch, the CG state never moves through
+                               HBM, workgroups meet at a grid barrier once per iteration; otherwise as 1.
+                             1: streaming -- one fused launch per CG iteration.
                              0: two launches per iteration, argmin's recurrences to the letter              */
     int32_t precision;    /* 0 (default): fp64 everywhere, as the reference.  1: the CG state, the operator and
                              (tile-relative) coordinates in fp32, dot products accumulated in fp64 -- the fp32
@@ -145,6 +149,9 @@ typedef struct mag_stats {
     int64_t halo_nodes;  /* sum over tiles of nodes staged from other tiles */
     int32_t max_tile_halo;
     int32_t lds_operator; /* 1: LDS-halo operator ran, 0: global-gather fallback */
+    int32_t cg_kernel;    /* what ran the CG: 0 two launches per iteration, 1 one fused launch per iteration,
+                             2 on-chip single launch, 3 CSR operator, 4 fp32 leg */
+    int32_t reserved;
     /* per-phase device time, HIP events on the context's stream, milliseconds */
     double ms_order;     /* Hilbert ordering + incidence + tile tables (symbolic, matrix-free op) */
     double ms_csr_symbolic;

@@ -111,6 +111,10 @@ struct mag_ctx {
     int32_t g_all = 1; // ... of the rank with the most tiles: dot-partial slots of the exchange buffer (multi-GPU)
     size_t cwords = 0; // doubles per exchange buffer: nsums * g_all + 2 * n_iface
     bool pre = false;  // mag_options.preconditioner != 0
+    // on-chip CG (cg.hip, k_cg_persist): the whole solve in one launch when every tile fits registers + LDS
+    bool persist = false, persist_failed = false;
+    int32_t persist_k = 0, persist_grid = 0, persist_maxh = 0, cg_kernel = 0;
+    DevBuf qx, wg_part, grp_part, psync;
     int nsums() const { return pre ? 5 : 4; }
     DevBuf xy32, hxy32, rqp32a, rqp32b, x32; // fp32 leg (mag_options.precision = 1)
     hipGraphExec_t graph = nullptr;
@@ -369,6 +373,7 @@ int ensure_order(mag_ctx *ctx)
         HIPCHK(ctx->tmeta.reserve(sizeof(magk::TileMeta) * (size_t)T));
         magk::tile_meta(ctx->tile_rdeg.as<int32_t>(), ctx->tile_off.as<int64_t>(), ctx->tile_hoff.as<int32_t>(), T,
                         ctx->tmeta.as<magk::TileMeta>(), s);
+        magk::mark_published(ctx->halo_g.as<int32_t>(), ctx->halo_total, ctx->maskP.as<uint8_t>(), s);
     } else {
         HIPCHK(ctx->ell.reserve(8 * (size_t)(h_total > 0 ? h_total : 1)));
         magk::fill_ell(ctx->inc_off.as<int32_t>(), ctx->inc.as<uint32_t>(), ctx->conn.as<int32_t>(),
@@ -376,6 +381,27 @@ int ensure_order(mag_ctx *ctx)
                        ctx->ell.as<int2>(), s);
     }
     HIPCHK(hipGetLastError());
+    // on-chip CG: every tile resident at once (one workgroup per CU, kPersistNpt * 512 / B tiles each)
+    ctx->persist = false;
+    if (ctx->opt.cg_variant == 2 && ctx->use_lds && !ctx->dist && !ctx->persist_failed && ctx->opt.precision == 0 &&
+        ctx->opt.preconditioner == 0 && ctx->opt.cg_operator == MAG_OP_MATRIX_FREE && max_halo <= B) {
+        int dev = 0, cus = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const int kmax = magk::persist_tiles_per_wg(B);
+        const int k = cus > 0 ? (T + cus - 1) / cus : 0;
+        // Below three tiles per workgroup the grid barrier (~8 us) costs more than re-streaming the state does
+        // (measured crossover at ~700 tiles of 512 nodes); tests lower the bar to reach the kernel with small meshes.
+        int kmin = 3;
+        if (const char *e = getenv("MAG_TUNE_PERSIST_MIN_K")) kmin = atoi(e);
+        ctx->persist_maxh = ((max_halo + 3) / 4) * 4;
+        if (kmax > 0 && k >= 1 && k >= kmin && k <= kmax && (T + k - 1) / k <= 256 && // the gather holds 256 records
+            magk::persist_lds_bytes(B, ctx->cap, ctx->persist_maxh) <= 160 * 1024) {
+            ctx->persist = true;
+            ctx->persist_k = k;
+            ctx->persist_grid = (T + k - 1) / k;
+        }
+    }
     ctx->have_order = true;
     return MAG_OK;
 }
@@ -904,6 +930,74 @@ int cg_phase_fused(mag_ctx *ctx)
     return MAG_OK;
 }
 
+// ---- on-chip variant: ONE launch for the whole solve (cg.hip, k_cg_persist) ----
+int cg_phase_persist(mag_ctx *ctx)
+{
+    using magk::FusedState;
+    hipStream_t s = ctx->stream;
+    const int grid = ctx->persist_grid;
+    HIPCHK(ctx->fstate.reserve(sizeof(FusedState)));
+    HIPCHK(ctx->qx.reserve(2 * 16 * (size_t)ctx->N));
+    HIPCHK(ctx->wg_part.reserve(2 * 4 * 8 * (size_t)grid));
+    HIPCHK(ctx->grp_part.reserve(2 * 8 * 4 * 8));
+    HIPCHK(ctx->psync.reserve(64));
+    HIPCHK(hipMemsetAsync(ctx->psync.p, 0, 64, s)); // arrival counters, timeout word: zeroed before EVERY launch
+    HIPCHK(hipMemsetAsync(ctx->fstate.p, 0, sizeof(FusedState), s));
+    magk::PersistParams P = {};
+    P.N = ctx->N;
+    P.T = ctx->T;
+    P.tiles_per_wg = ctx->persist_k;
+    P.cap = ctx->cap;
+    P.maxh = ctx->persist_maxh;
+    P.hist_len = ctx->opt.history_len;
+    P.stop_mode = ctx->opt.stop_mode;
+    // ~0.3 s of polling (each poll is a memory round trip) before a workgroup concludes that the grid is not resident
+    P.spin_limit = 1u << 19;
+    if (const char *e = getenv("MAG_TUNE_PERSIST_SPIN")) P.spin_limit = (uint32_t)atoi(e); // tests: force the fallback
+    P.max_iter = (long long)ctx->opt.max_iter;
+    P.tol = ctx->opt.tol;
+    P.c0 = ctx->youngs * ctx->thick / (2.0 * (1.0 - ctx->nu * ctx->nu));
+    P.nu = ctx->nu;
+    P.h = (1.0 - ctx->nu) / 2.0;
+    P.xyP = ctx->xyP.as<double2>();
+    P.maskP = ctx->maskP.as<uint8_t>();
+    P.meta = ctx->tmeta.as<magk::TileMeta>();
+    P.ell16 = ctx->ell.as<uint32_t>();
+    P.halo_g = ctx->halo_g.as<int32_t>();
+    P.halo_xy = ctx->halo_xy.as<double2>();
+    P.bP = ctx->bP.as<double2>();
+    P.x = ctx->x.as<double2>();
+    P.qx = ctx->qx.as<double2>();
+    P.wg_part = ctx->wg_part.as<double>();
+    P.grp_part = ctx->grp_part.as<double>();
+    P.sync = ctx->psync.as<uint32_t>();
+    P.st = ctx->fstate.as<FusedState>();
+    P.hist = ctx->hist.as<double>();
+    magk::persist_launch(P, ctx->B, grid, s);
+    HIPCHK(hipGetLastError());
+    uint32_t h_sync[16] = {};
+    HIPCHK(hipMemcpyAsync(&ctx->h_fstate[2], ctx->fstate.p, sizeof(FusedState), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(h_sync, ctx->psync.p, 64, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const FusedState &st = ctx->h_fstate[2];
+    if (h_sync[9] != 0 || !st.done) {
+        // a workgroup gave up waiting at the grid barrier (not every workgroup resident: the GPU is shared with
+        // another process, or fewer CUs are usable than reported): use the streaming kernels from now on
+        ctx->persist_failed = true;
+        ctx->persist = false;
+        if (ctx->opt.verbose) printf("info: on-chip CG not co-resident, falling back to the streaming iteration\n");
+        ctx->cg_kernel = 1;
+        return cg_phase_fused(ctx);
+    }
+    ctx->cg_kernel = 2;
+    ctx->stats.iterations = st.iterations;
+    ctx->stats.final_cost = st.final_cost;
+    ctx->stats.rhs_norm = std::sqrt(st.bb);
+    ctx->stats.converged = st.converged;
+    ctx->stats.breakdown = st.breakdown;
+    return MAG_OK;
+}
+
 // solver.rs:365-404,427-432,123-137 on the device: K_ff (exact zeros dropped) + b in compact unknown numbering
 int build_reduced(mag_ctx *ctx, bool fill)
 {
@@ -1120,7 +1214,7 @@ void mag_default_options(mag_options *o)
     o->history_len = 0;
     o->verbose = 0;
     o->op_variant = 0;
-    o->cg_variant = 1;
+    o->cg_variant = 2;
     o->precision = 0;
     o->preconditioner = 0;
 }
@@ -1302,8 +1396,11 @@ int mag_run(mag_ctx *ctx)
         return fail(ctx, MAG_ERR_BAD_ARGS,
                     "preconditioner needs the fused LDS iteration: cg_variant 1, precision fp64, matrix-free operator, "
                     "every tile within LDS");
+    ctx->cg_kernel = csr_op ? 3 : (f32 ? 4 : (ctx->fused ? 1 : 0));
     if (int rc = csr_op ? cg_phase_csr(ctx)
-                        : (f32 ? cg_phase_fused32(ctx) : (ctx->fused ? cg_phase_fused(ctx) : cg_phase(ctx))))
+                        : (f32 ? cg_phase_fused32(ctx)
+                               : (ctx->persist ? cg_phase_persist(ctx)
+                                               : (ctx->fused ? cg_phase_fused(ctx) : cg_phase(ctx)))))
         return rc;
     HIPCHK(hipEventRecord(ctx->ev[6], s));
     if (ctx->opt.verbose)
@@ -1344,6 +1441,7 @@ int mag_run(mag_ctx *ctx)
     st.halo_nodes = ctx->halo_total;
     st.max_tile_halo = ctx->max_halo;
     st.lds_operator = ctx->use_lds ? 1 : 0;
+    st.cg_kernel = ctx->cg_kernel;
     st.n_free = ctx->nf;
     ctx->have_run = true;
     if (st.breakdown)
@@ -1486,6 +1584,7 @@ int mag_time_operator(mag_ctx *ctx, int32_t reps, double *ms_per_launch)
     if (reps < 1 || !ms_per_launch) return fail(ctx, MAG_ERR_BAD_ARGS, "reps < 1 or null output");
     hipStream_t s = ctx->stream;
     if (ctx->fused) {
+        if (int rc = reserve_fused(ctx)) return rc; // an on-chip solve leaves the streaming buffers unallocated
         // the fused iteration kernel on a scratch state that never reports convergence: dots {1,1,0,0}
         magk::FusedState h = {};
         h.jslot[0] = h.jslot[1] = 5;

@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(B) k_operator(const OpParams P)
 // is issued up front.  Slot words of the first 8 incident elements are prefetched into registers.
 constexpr int kSlotRegs = 5; // ring words kept in registers: 10 entries, a closed fan of valence <= 9
 
-// One word of the ring table (symbolic.hip, k_ring16): two 16-bit entries -- tile-local id in bits 0-10, bit 15 = no
+// One word of the ring table (symbolic.hip, k_ring16): two 16-bit entries -- tile-local id in bits 0-11, bit 15 = no
 // triangle between the previous entry and this one, 0xffff = end.  Every other consecutive pair (prev, cur) is the
 // triangle (a, prev, cur): one LDS gather per entry instead of two per triangle.
 // The walk carries everything RELATIVE to the centre node a (d = c - c_a, u = p - p_a), computed once per neighbour.
@@ -300,7 +300,7 @@ __device__ inline void ring_word(uint32_t ww, const V2 *s_xy, const V2 *s_p, con
     for (int half = 0; half < 2; ++half) {
         const uint32_t e = half ? (ww >> 16) : (ww & 0xffffu);
         if (e != 0xffffu) {
-            const uint32_t id = e & 0x7ffu;
+            const uint32_t id = e & 0xfffu;
             const V2 cxy = s_xy[id], cp = s_p[id];
             V2 d, u;
             d.x = cxy.x - ca.x;
@@ -1942,6 +1942,336 @@ void rhs_from_apply(const double *yP, const double *f_in, const uint8_t *u_known
                     double *bP, hipStream_t s)
 {
     k_rhs_from_apply<<<blocks_for(2 * N, 256), 256, 0, s>>>(yP, f_in, u_known, perm, N, bP);
+}
+
+
+// ============================================ on-chip (persistent) CG ===
+// When the whole mesh fits the chip -- every workgroup keeps 2 * (1024 / B) tiles: r, q, p, x of their nodes in
+// registers, coordinates and the p image in LDS, the ring words in registers -- the CG state never moves through
+// HBM again: ONE launch runs the whole solve.  Per iteration a workgroup only publishes q of the nodes other tiles
+// read (write-through) and four dot partials, and every workgroup meets at a grid barrier: arrivals are counted on
+// eight words (b % 8: a label that spreads the atomics, not a placement), one wave per workgroup polls all eight,
+// then every workgroup reads every workgroup's partial record and sums them in one fixed order -- the same bits in
+// every workgroup, so all of them take the same stop decision in the same iteration.  Inter-workgroup traffic follows the hand-off rules of the
+// CDNA4 guide: payload stored sc1 and drained before the arrival atomic, EVERY load of handed-off bytes an sc1
+// buffer load, the polled word written by atomics only, spins bounded (a workgroup that gives up sets the timeout
+// word and leaves; the host then falls back to the streaming kernels).  Same recurrences and state machine as
+// k_cg_fused (alpha, beta from the four exact sums of the previous iterate).
+typedef __attribute__((address_space(1))) unsigned int gu32;
+constexpr int kPersistThreads = 512; // 8 waves per CU = 2 per SIMD: 256 VGPRs per lane, no spills with 4 nodes per thread
+constexpr int kPersistGroups = 8;
+
+__device__ inline double2 load2_sc1(const double2 *base, int64_t n_items, int64_t idx)
+{
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, (short)0, (int)(n_items * 16), 0x00020000);
+    const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(idx * 16), 0, 16);
+    double2 v;
+    __builtin_memcpy(&v, &d, 16);
+    return v;
+}
+
+// Grid barrier, arrival side + wait.  The workgroup's payload (its partial record, q of its published nodes) must
+// have been stored sc1; every storing wave drains here, then ONE lane adds to the group's arrival word (fire and
+// forget) and one wave polls the eight words until each holds gsize * epoch.  Returns false on timeout.
+__device__ inline bool persist_arrive_wait(const PersistParams &P, unsigned epoch, int *s_flag)
+{
+    const int tid = threadIdx.x;
+    const int grid = gridDim.x;
+    const int ngroups = grid < kPersistGroups ? grid : kPersistGroups;
+    gu32 *sync = (gu32 *)P.sync;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: payload drained before the arrival
+    __syncthreads();
+    if (tid < 64) {
+        if (tid == 0)
+            __hip_atomic_fetch_add(sync + (blockIdx.x % ngroups), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int g = tid < ngroups ? tid : 0;
+        const unsigned want = (unsigned)((grid - g + ngroups - 1) / ngroups) * epoch;
+        int ok = 0;
+        for (unsigned spins = 0; spins < P.spin_limit; ++spins) {
+            const unsigned v = __hip_atomic_load(sync + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all(v >= want)) {
+                ok = 1;
+                break;
+            }
+            if (__hip_atomic_load(sync + kPersistGroups + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (tid == 0) {
+            if (!ok) __hip_atomic_store(sync + kPersistGroups + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *s_flag = ok;
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // compiler only: nothing below moves above the poll
+    return *s_flag != 0;
+}
+
+// Grid barrier, reduction side: every workgroup reads every workgroup's partial record (sc1 loads, one 16-byte
+// piece per thread) and sums them in a fixed two-level order -- chunks of eight records, then the chunks -- so all
+// workgroups hold the same bits.  grid <= 256.
+__device__ inline void persist_gather_sums(const PersistParams &P, int par, double *s_S, double2 *s_rec, double *s_chunk)
+{
+    const int tid = threadIdx.x;
+    const int grid = gridDim.x;
+    if (tid < 2 * grid)
+        s_rec[tid] = load2_sc1((const double2 *)P.wg_part, 2 * 2 * (int64_t)grid, 2 * (int64_t)par * grid + tid);
+    __syncthreads();
+    if (tid < 4 * 32) {
+        const int c = tid & 3, k = tid >> 2;
+        const double *rec = (const double *)s_rec;
+        double t = 0.0;
+        const int end = 8 * k + 8 < grid ? 8 * k + 8 : grid;
+        for (int m = 8 * k; m < end; ++m) t += rec[4 * m + c];
+        s_chunk[4 * k + c] = t;
+    }
+    __syncthreads();
+    if (tid < 4) {
+        double t = 0.0;
+        const int nchunks = (grid + 7) / 8;
+        for (int k = 0; k < nchunks; ++k) t += s_chunk[4 * k + tid];
+        s_S[tid] = t;
+    }
+    __syncthreads();
+}
+
+constexpr int kPersistRegs = 4; // ring words in registers per node: 8 entries, a closed fan of valence <= 7
+constexpr int kPersistNpt = 4;  // nodes (tiles) per thread
+
+template <int B>
+__global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistParams P)
+{
+    constexpr int TG = kPersistThreads / B; // thread groups; each owns kPersistNpt of the workgroup's tiles
+    constexpr int NPT = kPersistNpt;
+    extern __shared__ __attribute__((aligned(16))) double2 smem[];
+    const int tid = threadIdx.x, gi = tid / B, lt = tid % B;
+    const int cap = P.cap, maxh = P.maxh;
+    // LDS per local tile l: coordinates[cap], p image[cap] (owned part = the CG vector p itself), halo r[maxh],
+    // halo p[maxh], x[B].  Registers per node: r, q, the ring words.
+    const int tile_words = 2 * cap + 2 * maxh + B;
+    double2 *s_rec = smem + (size_t)NPT * TG * tile_words; // 2 * grid pieces of the partial records
+    double *s_red = (double *)(s_rec + 2 * 256);
+    double *s_S = s_red + 4 * (kPersistThreads / 64);
+    double *s_chunk = s_S + 4;
+    int *s_flag = (int *)(s_chunk + 4 * 32);
+    auto t_xy = [&](int s) { return smem + (size_t)(gi + TG * s) * tile_words; };
+
+    int32_t node[NPT], hg[NPT], deg[NPT];
+    uint32_t flags[NPT]; // bit 0/1 prescribed ux/uy, 2 published, 3 live tile, 4 valid node, 5 halo lane
+    uint32_t w[NPT][kPersistRegs];
+    int64_t ell_off[NPT];
+    double2 r[NPT], q[NPT];
+
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < NPT; ++s) {
+        const int l = gi + TG * s;
+        const int32_t t = blockIdx.x * P.tiles_per_wg + l;
+        double2 *xy = t_xy(s), *pim = xy + cap, *hr = pim + cap, *hp = hr + maxh, *xs = hp + maxh;
+        node[s] = 0;
+        hg[s] = 0;
+        deg[s] = 0;
+        flags[s] = 3;
+        ell_off[s] = 0;
+        r[s] = q[s] = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < kPersistRegs; ++k) w[s][k] = 0xffffffffu;
+        if (!(l < P.tiles_per_wg && t < P.T)) continue;
+        const TileMeta tm = P.meta[t];
+        const int64_t nd = (int64_t)t * B + lt;
+        node[s] = (int32_t)nd;
+        flags[s] = 8;
+        if (nd < P.N) {
+            const double2 b = P.bP[nd];
+            r[s] = make_double2(-b.x, -b.y);
+            xy[lt] = P.xyP[nd];
+            flags[s] |= 16u | (uint32_t)(P.maskP[nd] & 7);
+            acc[0] += b.x * b.x + b.y * b.y;
+        } else {
+            xy[lt] = make_double2(0.0, 0.0);
+            flags[s] |= 3;
+        }
+        pim[lt] = make_double2(0.0, 0.0);
+        xs[lt] = make_double2(0.0, 0.0);
+        deg[s] = tm.deg;
+        ell_off[s] = tm.ell_off + lt;
+#pragma unroll
+        for (int k = 0; k < kPersistRegs; ++k)
+            if (k < deg[s]) w[s][k] = P.ell16[ell_off[s] + (int64_t)k * B];
+        if (lt < tm.nh) {
+            flags[s] |= 32;
+            hg[s] = P.halo_g[tm.hoff + lt];
+            xy[B + lt] = P.halo_xy[tm.hoff + lt];
+            const double2 hb = P.bP[hg[s]];
+            hr[lt] = make_double2(-hb.x, -hb.y);
+            hp[lt] = make_double2(0.0, 0.0);
+        }
+        if ((flags[s] & 20) == 20) store2<true>(P.qx, 2 * P.N, nd, make_double2(0.0, 0.0)); // q_{-1} = 0, parity 0
+    }
+    if (blockIdx.x == 0 && tid == 0) acc[1] = 1.0; // "p.q" > 0: alpha finite, multiplies q = 0
+    block_sumN<kPersistThreads, 4>(acc, s_red);
+    int par = 0;
+    if (tid == 0) {
+        double2 *dst = (double2 *)P.wg_part;
+        store2<true>(dst, 2 * 2 * (int64_t)gridDim.x, 2 * ((int64_t)par * gridDim.x + blockIdx.x), make_double2(acc[0], acc[1]));
+        store2<true>(dst, 2 * 2 * (int64_t)gridDim.x, 2 * ((int64_t)par * gridDim.x + blockIdx.x) + 1,
+                     make_double2(acc[2], acc[3]));
+    }
+    unsigned epoch = 1;
+    if (!persist_arrive_wait(P, epoch, s_flag)) return;
+    double2 hq[NPT]; // q of this thread's halo nodes, fetched while the sums are gathered
+    auto fetch_halo_q = [&]() {
+#pragma unroll
+        for (int s = 0; s < NPT; ++s)
+            hq[s] = (flags[s] & 32) ? load2_sc1(P.qx, 2 * P.N, (int64_t)par * P.N + hg[s]) : make_double2(0.0, 0.0);
+    };
+    fetch_halo_q();
+    persist_gather_sums(P, par, s_S, s_rec, s_chunk);
+
+    const double c0 = P.c0, nu = P.nu, h = P.h;
+    double target = P.tol, bb = 0.0;
+    long long j = 0;
+    int verdict = 0; // 1 converged, 2 iteration cap, 3 non-finite
+    double cost = 0.0;
+    for (;;) {
+        const double S0 = s_S[0], S1 = s_S[1], S2 = s_S[2], S3 = s_S[3];
+        if (j == 0) {
+            bb = S0;
+            target = P.stop_mode == 2 ? P.tol * sqrt(bb) : P.tol;
+        }
+        const double rr = S0;
+        cost = P.stop_mode == 1 ? fabs(rr) : sqrt(rr);
+        const long long it_done = j - 1;
+        if (blockIdx.x == 0 && tid == 0 && it_done >= 1 && it_done - 1 < P.hist_len) P.hist[it_done - 1] = cost;
+        if (j == 0 && bb == 0.0) {
+            verdict = 1;
+            cost = 0.0;
+            break;
+        }
+        if (it_done >= 1 && cost <= target) verdict = 1;
+        else if (!(fabs(rr) <= 1.79769313486231570e308)) verdict = 3;
+        else if (it_done >= P.max_iter) verdict = 2;
+        if (verdict) break;
+        const double alpha = rr / S1;
+        const double beta = (rr + 2.0 * alpha * S2 + alpha * alpha * S3) / rr;
+
+        // ---- vector updates: r in registers, p and x in LDS, halo copies in LDS (their q from the publishers)
+#pragma unroll
+        for (int s = 0; s < NPT; ++s) {
+            if (!(flags[s] & 8)) continue;
+            double2 *xy = t_xy(s), *pim = xy + cap, *hr = pim + cap, *hp = hr + maxh, *xs = hp + maxh;
+            const double2 po = pim[lt];
+            double2 xo = xs[lt], pn;
+            xo.x += alpha * po.x;
+            xo.y += alpha * po.y;
+            xs[lt] = xo;
+            r[s].x += alpha * q[s].x;
+            r[s].y += alpha * q[s].y;
+            pn.x = -r[s].x + beta * po.x;
+            pn.y = -r[s].y + beta * po.y;
+            pim[lt] = pn;
+            if (flags[s] & 32) {
+                double2 hrv = hr[lt], hpv = hp[lt];
+                hrv.x += alpha * hq[s].x;
+                hrv.y += alpha * hq[s].y;
+                hpv.x = -hrv.x + beta * hpv.x;
+                hpv.y = -hrv.y + beta * hpv.y;
+                hr[lt] = hrv;
+                hp[lt] = hpv;
+                pim[B + lt] = hpv;
+            }
+        }
+        __syncthreads();
+
+        // ---- q = M K M p on the owned nodes, dot partials, publication
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = 0.0;
+#pragma unroll
+        for (int s = 0; s < NPT; ++s) {
+            if (!(flags[s] & 8)) continue;
+            const double2 *xy = t_xy(s), *pim = xy + cap;
+            const double2 ca = xy[lt], pa = pim[lt];
+            double fx = 0.0, fy = 0.0;
+            {
+                double2 rd = ca, ru = pa;
+                auto tri = [&](const double2 db, const double2 ub, const double2 dc, const double2 uc) {
+                    fan_force<double2, double>(db, ub, dc, uc, c0, nu, h, fx, fy);
+                };
+#pragma unroll
+                for (int k = 0; k < kPersistRegs; ++k) ring_word(w[s][k], xy, pim, ca, pa, rd, ru, tri);
+                for (int32_t k = kPersistRegs; k < deg[s]; ++k)
+                    ring_word(P.ell16[ell_off[s] + (int64_t)k * B], xy, pim, ca, pa, rd, ru, tri);
+            }
+            if ((flags[s] & 1) || !(flags[s] & 16)) fx = 0.0;
+            if ((flags[s] & 2) || !(flags[s] & 16)) fy = 0.0;
+            q[s] = make_double2(fx, fy);
+            if ((flags[s] & 20) == 20) store2<true>(P.qx, 2 * P.N, (int64_t)(par ^ 1) * P.N + node[s], q[s]);
+            acc[0] += r[s].x * r[s].x + r[s].y * r[s].y;
+            acc[1] += pa.x * fx + pa.y * fy;
+            acc[2] += r[s].x * fx + r[s].y * fy;
+            acc[3] += fx * fx + fy * fy;
+        }
+        block_sumN<kPersistThreads, 4>(acc, s_red);
+        par ^= 1;
+        if (tid == 0) {
+            double2 *dst = (double2 *)P.wg_part;
+            store2<true>(dst, 2 * 2 * (int64_t)gridDim.x, 2 * ((int64_t)par * gridDim.x + blockIdx.x),
+                         make_double2(acc[0], acc[1]));
+            store2<true>(dst, 2 * 2 * (int64_t)gridDim.x, 2 * ((int64_t)par * gridDim.x + blockIdx.x) + 1,
+                         make_double2(acc[2], acc[3]));
+        }
+        ++epoch;
+        ++j;
+        if (!persist_arrive_wait(P, epoch, s_flag)) return;
+        fetch_halo_q();
+        persist_gather_sums(P, par, s_S, s_rec, s_chunk);
+    }
+    // x of iterate j-1 is in LDS; the verdict is the same in every workgroup
+#pragma unroll
+    for (int s = 0; s < NPT; ++s)
+        if ((flags[s] & 24) == 24) P.x[node[s]] = (t_xy(s) + 2 * cap + 2 * maxh)[lt];
+    if (blockIdx.x == 0 && tid == 0) {
+        FusedState *st = P.st;
+        st->bb = bb;
+        st->target = target;
+        st->iterations = j - 1 < 0 ? 0 : j - 1;
+        st->final_cost = cost;
+        st->converged = verdict == 1 ? 1 : 0;
+        st->breakdown = verdict == 3 ? 1 : 0;
+        st->done = 1;
+    }
+}
+
+int persist_tiles_per_wg(int32_t B) { return B == 256 || B == 512 ? kPersistNpt * (kPersistThreads / B) : 0; }
+
+size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh)
+{
+    const size_t tiles = (size_t)kPersistNpt * (kPersistThreads / B);
+    return tiles * (2 * (size_t)cap + 2 * (size_t)maxh + (size_t)B) * 16 + 2 * 256 * 16 +
+           (4 * (kPersistThreads / 64) + 4 + 4 * 32) * 8 + 16;
+}
+
+void persist_launch(const PersistParams &P, int32_t B, int32_t grid, hipStream_t s)
+{
+    const size_t lds = persist_lds_bytes(B, P.cap, P.maxh);
+    if (B == 256)
+        k_cg_persist<256><<<grid, kPersistThreads, lds, s>>>(P);
+    else
+        k_cg_persist<512><<<grid, kPersistThreads, lds, s>>>(P);
+}
+
+// bit 2 of the node mask: some tile reads this node through its halo list, so its owner must publish q
+__global__ void __launch_bounds__(256) k_mark_published(const int32_t *halo_g, int64_t halo_total, uint8_t *maskP)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= halo_total) return;
+    // byte-wide atomic OR does not exist; neighbouring bytes belong to other nodes, so OR the containing word
+    const int64_t g = halo_g[i];
+    atomicOr((unsigned int *)(maskP + (g & ~(int64_t)3)), 4u << (8 * (g & 3)));
+}
+
+void mark_published(const int32_t *halo_g, int64_t halo_total, uint8_t *maskP, hipStream_t s)
+{
+    if (halo_total > 0) k_mark_published<<<(unsigned)((halo_total + 255) / 256), 256, 0, s>>>(halo_g, halo_total, maskP);
 }
 
 } // namespace magk

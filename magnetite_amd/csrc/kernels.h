@@ -270,6 +270,34 @@ void fused_setup(const double *part, int32_t nPart, int32_t stride, int stop_mod
 void comm_slots(const int32_t *iface, int32_t n_iface, int32_t own0, int32_t own1, const int32_t *halo_g,
                 int64_t halo_total, int64_t N, int32_t *own_qslot, int32_t *halo_qslot, hipStream_t s);
 
+// ---- on-chip (persistent) CG: the whole solve in one launch when every tile fits registers + LDS (cg.hip) ----
+struct PersistParams {
+    int64_t N;
+    int32_t T, tiles_per_wg, cap, maxh, hist_len, stop_mode;
+    uint32_t spin_limit; // polls of the arrival words before a workgroup gives up (sets the timeout word, leaves)
+    uint32_t pad;
+    long long max_iter;
+    double tol, c0, nu, h;
+    const double2 *xyP;
+    const uint8_t *maskP; // bit 0/1: prescribed ux/uy, bit 2: read by some tile's halo (owner publishes q)
+    const TileMeta *meta;
+    const uint32_t *ell16;
+    const int32_t *halo_g;
+    const double2 *halo_xy;
+    const double2 *bP;
+    double2 *x;
+    double2 *qx;       // 2 * N: published q, by parity
+    double *wg_part;   // 2 * grid * 4: dot partials of every workgroup, by parity
+    double *grp_part;  // unused (kept for layout)
+    uint32_t *sync;    // [0..7] arrival counters, [9] timeout word; zeroed before every launch
+    FusedState *st;
+    double *hist;
+};
+int persist_tiles_per_wg(int32_t B); // tiles one workgroup keeps on chip (0: tile size not supported)
+size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh);
+void persist_launch(const PersistParams &P, int32_t B, int32_t grid, hipStream_t s);
+void mark_published(const int32_t *halo_g, int64_t halo_total, uint8_t *maskP, hipStream_t s);
+
 // ---- fp32 leg of BASELINE config 5 (fp64 vs fp32 CG tolerance sweep): the fused iteration with the CG state, the
 // operator arithmetic and TILE-RELATIVE coordinates in fp32; dot products accumulate in fp64 ----
 struct Rqp32 {

@@ -728,3 +728,78 @@ def test_timing_hooks_report_plausible_launch_times(built):
             c.upload_problem(p)
             c.run()
             assert c.time_operator(20) > 0
+
+
+# ---- on-chip single-launch CG (cg_variant 2, the default when the mesh fits the chip) ----
+def test_on_chip_cg_matches_the_oracle(built, monkeypatch):
+    """k_cg_persist: the whole solve in one launch, workgroups meeting at a grid barrier every iteration.  The library
+    picks it by itself only for 3-4 tiles of 512 nodes per CU (0.5-1M triangles); MAG_TUNE_PERSIST_MIN_K=1 lets small
+    meshes reach it: one workgroup, a few workgroups, workgroups with unequal tile counts, both tile sizes, every stop
+    mode, the iteration cap, the cost history and the zero right-hand side."""
+    monkeypatch.setenv("MAG_TUNE_PERSIST_MIN_K", "1")
+    cases = [("plate12", meshgen.config_fixed_left_pull_right(meshgen.plate(12)), 512),
+             ("hole48", meshgen.config_fixed_left_pull_right(meshgen.shuffle(meshgen.plate_with_holes(48), 7)), 256),
+             ("hole150", meshgen.config_fixed_left_point_load(meshgen.perturb(meshgen.plate_with_holes(150), 0.2, 4)), 512),
+             ("cw", meshgen.config_fixed_left_pull_right(meshgen.clockwise(meshgen.plate(20))), 512)]
+    for name, p, tile in cases:
+        ref = oracle_run(p, hist_len=50)
+        with Context(device=0, tile_nodes=tile, history_len=50) as c:
+            out = c.solve(p)
+            st = c.stats()
+            hist = c.history(min(50, out["iterations"]))
+        assert st["cg_kernel"] == 2, name
+        assert out["converged"] == 1 and abs(out["iterations"] - ref["iterations"]) <= max(3, ref["iterations"] // 50), name
+        for key in ("u", "f", "stress"):
+            assert rel(out[key], ref[key]) <= TOL_U, (name, key)
+        k = min(len(hist), len(ref["history"]), 30)
+        assert np.allclose(hist[:k], ref["history"][:k], rtol=1e-8), name
+    p = cases[2][1]
+    for mode, tol in ((MAG_STOP_REL, 1e-9), (MAG_STOP_RNORM_SQ, 1e-6)):
+        ref = oracle_run(p, stop_mode={MAG_STOP_REL: oracle.STOP_REL, MAG_STOP_RNORM_SQ: oracle.STOP_RNORM_SQ}[mode], tol=tol)
+        with Context(device=0, tile_nodes=512, stop_mode=mode, tol=tol) as c:
+            out = c.solve(p)
+            assert c.stats()["cg_kernel"] == 2
+        assert abs(out["iterations"] - ref["iterations"]) <= 5 and rel(out["u"], ref["u"]) <= TOL_U
+    with Context(device=0, tile_nodes=512, max_iter=37) as c:
+        out = c.solve(p, allow_not_converged=True)
+        assert c.stats()["cg_kernel"] == 2 and out["iterations"] == 37 and out["converged"] == 0
+    z = meshgen.Problem(p.mesh, p.u_known, 0.0 * p.u_in, 0.0 * p.f_in, p.youngs_modulus, p.poisson_ratio, p.part_thickness)
+    with Context(device=0, tile_nodes=512) as c:
+        out = c.solve(z)
+        assert out["iterations"] == 0 and out["converged"] == 1 and not out["u"].any()
+
+
+def test_on_chip_cg_is_chosen_for_the_benchmark_mesh_and_agrees_with_streaming(built):
+    """1M-triangle benchmark mesh: the default picks the on-chip kernel (4 tiles of 512 nodes per CU); the streaming
+    kernel (cg_variant 1) takes the same number of iterations and lands on the same displacements."""
+    p = meshgen.baseline_problem("hole1m")
+    with Context(device=0, stop_mode=MAG_STOP_REL, tol=1e-8) as c:
+        a = c.solve(p)
+        assert c.stats()["cg_kernel"] == 2
+        b = c.solve(p)
+    assert np.array_equal(a["u"], b["u"])                      # bitwise reproducible
+    with Context(device=0, stop_mode=MAG_STOP_REL, tol=1e-8, cg_variant=1) as c:
+        s = c.solve(p)
+        assert c.stats()["cg_kernel"] == 1
+    assert abs(a["iterations"] - s["iterations"]) <= 2
+    assert rel(a["u"], s["u"]) <= 1e-9
+
+
+def test_on_chip_cg_falls_back_when_the_grid_barrier_times_out(built, monkeypatch):
+    """A workgroup that does not see every arrival within its spin budget sets the timeout word and leaves (the grid
+    is not fully resident: GPU shared with another process).  MAG_TUNE_PERSIST_SPIN=0 makes every wait give up at
+    once: the solve must still come back correct, through the streaming kernels, and the context must stop trying."""
+    monkeypatch.setenv("MAG_TUNE_PERSIST_MIN_K", "1")
+    monkeypatch.setenv("MAG_TUNE_PERSIST_SPIN", "0")
+    p = meshgen.config_fixed_left_pull_right(meshgen.plate_with_holes(96))
+    ref = oracle_run(p)
+    with Context(device=0, tile_nodes=512) as c:
+        out = c.solve(p)
+        assert c.stats()["cg_kernel"] == 1
+        assert rel(out["u"], ref["u"]) <= TOL_U and out["iterations"] == ref["iterations"]
+        monkeypatch.delenv("MAG_TUNE_PERSIST_SPIN")
+        out = c.solve(p)
+        assert c.stats()["cg_kernel"] == 1                     # remembered for the life of the context
+    with Context(device=0, tile_nodes=512) as c:
+        c.solve(p)
+        assert c.stats()["cg_kernel"] == 2
