@@ -114,7 +114,7 @@ struct mag_ctx {
     // on-chip CG (cg.hip, k_cg_persist): the whole solve in one launch when every tile fits registers + LDS
     bool persist = false, persist_failed = false;
     int32_t persist_k = 0, persist_grid = 0, persist_maxh = 0, cg_kernel = 0;
-    DevBuf qx, wg_part, grp_part, psync;
+    DevBuf qx, wg_part, psync; // published-q granules, partial-record granules, timeout word
     int nsums() const { return pre ? 5 : 4; }
     DevBuf xy32, hxy32, rqp32a, rqp32b, x32; // fp32 leg (mag_options.precision = 1)
     hipGraphExec_t graph = nullptr;
@@ -937,11 +937,14 @@ int cg_phase_persist(mag_ctx *ctx)
     hipStream_t s = ctx->stream;
     const int grid = ctx->persist_grid;
     HIPCHK(ctx->fstate.reserve(sizeof(FusedState)));
-    HIPCHK(ctx->qx.reserve(2 * 16 * (size_t)ctx->N));
-    HIPCHK(ctx->wg_part.reserve(2 * 4 * 8 * (size_t)grid));
-    HIPCHK(ctx->grp_part.reserve(2 * 8 * 4 * 8));
+    const size_t qg_bytes = 2 * 32 * (size_t)ctx->N, rec_bytes = 2 * 64 * (size_t)grid;
+    HIPCHK(ctx->qx.reserve(qg_bytes));
+    HIPCHK(ctx->wg_part.reserve(rec_bytes));
     HIPCHK(ctx->psync.reserve(64));
-    HIPCHK(hipMemsetAsync(ctx->psync.p, 0, 64, s)); // arrival counters, timeout word: zeroed before EVERY launch
+    // tags of a previous solve must not look current: granules and the timeout word are zeroed before EVERY launch
+    HIPCHK(hipMemsetAsync(ctx->qx.p, 0, qg_bytes, s));
+    HIPCHK(hipMemsetAsync(ctx->wg_part.p, 0, rec_bytes, s));
+    HIPCHK(hipMemsetAsync(ctx->psync.p, 0, 64, s));
     HIPCHK(hipMemsetAsync(ctx->fstate.p, 0, sizeof(FusedState), s));
     magk::PersistParams P = {};
     P.N = ctx->N;
@@ -967,9 +970,8 @@ int cg_phase_persist(mag_ctx *ctx)
     P.halo_xy = ctx->halo_xy.as<double2>();
     P.bP = ctx->bP.as<double2>();
     P.x = ctx->x.as<double2>();
-    P.qx = ctx->qx.as<double2>();
-    P.wg_part = ctx->wg_part.as<double>();
-    P.grp_part = ctx->grp_part.as<double>();
+    P.qg = ctx->qx.as<unsigned long long>();
+    P.recg = ctx->wg_part.as<unsigned long long>();
     P.sync = ctx->psync.as<uint32_t>();
     P.st = ctx->fstate.as<FusedState>();
     P.hist = ctx->hist.as<double>();

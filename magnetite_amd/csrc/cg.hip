@@ -1949,73 +1949,97 @@ void rhs_from_apply(const double *yP, const double *f_in, const uint8_t *u_known
 // When the whole mesh fits the chip -- every workgroup keeps 2 * (1024 / B) tiles: r, q, p, x of their nodes in
 // registers, coordinates and the p image in LDS, the ring words in registers -- the CG state never moves through
 // HBM again: ONE launch runs the whole solve.  Per iteration a workgroup only publishes q of the nodes other tiles
-// read (write-through) and four dot partials, and every workgroup meets at a grid barrier: arrivals are counted on
-// eight words (b % 8: a label that spreads the atomics, not a placement), one wave per workgroup polls all eight,
-// then every workgroup reads every workgroup's partial record and sums them in one fixed order -- the same bits in
-// every workgroup, so all of them take the same stop decision in the same iteration.  Inter-workgroup traffic follows the hand-off rules of the
-// CDNA4 guide: payload stored sc1 and drained before the arrival atomic, EVERY load of handed-off bytes an sc1
-// buffer load, the polled word written by atomics only, spins bounded (a workgroup that gives up sets the timeout
-// word and leaves; the host then falls back to the streaming kernels).  Same recurrences and state machine as
+// read and its four dot partials, as tagged granules (below); every workgroup then sweeps every workgroup's record
+// and the q of its own halo nodes until all tags carry the iteration's epoch -- that sweep IS the grid barrier -- and
+// sums the records in one fixed order: the same bits in every workgroup, so all of them take the same stop decision
+// in the same iteration.  Spins are bounded (a workgroup that gives up sets the timeout word and leaves; the host
+// then falls back to the streaming kernels).  Same recurrences and state machine as
 // k_cg_fused (alpha, beta from the four exact sums of the previous iterate).
 typedef __attribute__((address_space(1))) unsigned int gu32;
 constexpr int kPersistThreads = 512; // 8 waves per CU = 2 per SIMD: 256 VGPRs per lane, no spills with 4 nodes per thread
-constexpr int kPersistGroups = 8;
 
-__device__ inline double2 load2_sc1(const double2 *base, int64_t n_items, int64_t idx)
+// Inter-workgroup exchange by self-validating granules (CDNA4 guide, Guideline 16 R2: "the data IS the flag"): every
+// handed-off 32-bit half travels in its own naturally aligned 8-byte word {tag = epoch, value}, written by ONE relaxed
+// agent-scope atomic store and read by relaxed agent-scope atomic loads until the tag matches.  No arrival counters,
+// no store drains, no fences: a reader can never take a stale or torn value for the current one.  Two buffers by
+// parity: nobody can be two epochs ahead of a workgroup that has not finished reading (it would need that workgroup's
+// next record first).
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+__device__ inline void put_granules(unsigned long long *g, unsigned epoch, double2 v)
 {
-    auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, (short)0, (int)(n_items * 16), 0x00020000);
-    const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(idx * 16), 0, 16);
-    double2 v;
-    __builtin_memcpy(&v, &d, 16);
-    return v;
+    unsigned w[4];
+    __builtin_memcpy(w, &v, 16);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        __hip_atomic_store((gu64 *)g + k, ((unsigned long long)epoch << 32) | w[k], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Grid barrier, arrival side + wait.  The workgroup's payload (its partial record, q of its published nodes) must
-// have been stored sc1; every storing wave drains here, then ONE lane adds to the group's arrival word (fire and
-// forget) and one wave polls the eight words until each holds gsize * epoch.  Returns false on timeout.
-__device__ inline bool persist_arrive_wait(const PersistParams &P, unsigned epoch, int *s_flag)
+__device__ inline bool get_granules(const unsigned long long *g, unsigned epoch, double2 &v)
 {
-    const int tid = threadIdx.x;
-    const int grid = gridDim.x;
-    const int ngroups = grid < kPersistGroups ? grid : kPersistGroups;
-    gu32 *sync = (gu32 *)P.sync;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every storing wave: payload drained before the arrival
-    __syncthreads();
-    if (tid < 64) {
-        if (tid == 0)
-            __hip_atomic_fetch_add(sync + (blockIdx.x % ngroups), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int g = tid < ngroups ? tid : 0;
-        const unsigned want = (unsigned)((grid - g + ngroups - 1) / ngroups) * epoch;
-        int ok = 0;
-        for (unsigned spins = 0; spins < P.spin_limit; ++spins) {
-            const unsigned v = __hip_atomic_load(sync + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all(v >= want)) {
-                ok = 1;
-                break;
-            }
-            if (__hip_atomic_load(sync + kPersistGroups + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-        if (tid == 0) {
-            if (!ok) __hip_atomic_store(sync + kPersistGroups + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *s_flag = ok;
-        }
+    unsigned long long x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = __hip_atomic_load((gu64 *)g + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned w[4];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ok &= (unsigned)(x[k] >> 32) == epoch;
+        w[k] = (unsigned)x[k];
     }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // compiler only: nothing below moves above the poll
-    return *s_flag != 0;
+    __builtin_memcpy(&v, w, 16);
+    return ok;
 }
 
-// Grid barrier, reduction side: every workgroup reads every workgroup's partial record (sc1 loads, one 16-byte
-// piece per thread) and sums them in a fixed two-level order -- chunks of eight records, then the chunks -- so all
-// workgroups hold the same bits.  grid <= 256.
-__device__ inline void persist_gather_sums(const PersistParams &P, int par, double *s_S, double2 *s_rec, double *s_chunk)
+// Wait for epoch `epoch`: every workgroup's partial record (two 16-byte pieces each, one per thread) and the q of this
+// thread's halo nodes, swept together until every tag matches; then the records are summed in one fixed two-level
+// order (chunks of eight workgroups, then the chunks) so that all workgroups hold the same bits.  grid <= 256.
+// Returns false when the spin budget runs out (some workgroup is not running): the timeout word is set for the host.
+template <int NPT>
+__device__ inline bool persist_exchange(const PersistParams &P, int par, unsigned epoch, const uint32_t (&flags)[NPT],
+                                        const int32_t (&hg)[NPT], double2 (&hq)[NPT], double *s_S, double2 *s_rec,
+                                        double *s_chunk)
 {
     const int tid = threadIdx.x;
     const int grid = gridDim.x;
-    if (tid < 2 * grid)
-        s_rec[tid] = load2_sc1((const double2 *)P.wg_part, 2 * 2 * (int64_t)grid, 2 * (int64_t)par * grid + tid);
-    __syncthreads();
+    bool have_rec = tid >= 2 * grid, have_h[NPT];
+#pragma unroll
+    for (int s = 0; s < NPT; ++s) {
+        have_h[s] = !(flags[s] & 32);
+        hq[s] = make_double2(0.0, 0.0);
+    }
+    gu32 *tmo = (gu32 *)P.sync + 9;
+    bool done = false;
+    for (unsigned spins = 0; spins < P.spin_limit; ++spins) {
+        bool ok = true;
+        if (!have_rec) {
+            double2 v;
+            have_rec = get_granules(P.recg + 4 * (2 * (int64_t)par * grid + tid), epoch, v);
+            if (have_rec) s_rec[tid] = v;
+            ok &= have_rec;
+        }
+#pragma unroll
+        for (int s = 0; s < NPT; ++s)
+            if (!have_h[s]) {
+                have_h[s] = get_granules(P.qg + 4 * ((int64_t)par * P.N + hg[s]), epoch, hq[s]);
+                ok &= have_h[s];
+            }
+        if (__syncthreads_and(ok ? 1 : 0)) {
+            done = true;
+            break;
+        }
+        if ((spins & 255u) == 255u) { // somebody else gave up: do not wait for a grid that will never be complete
+            const int dead =
+                tid == 0 && __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ? 1 : 0;
+            if (__syncthreads_or(dead)) break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (!done) {
+        if (tid == 0) __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+    }
     if (tid < 4 * 32) {
         const int c = tid & 3, k = tid >> 2;
         const double *rec = (const double *)s_rec;
@@ -2032,6 +2056,7 @@ __device__ inline void persist_gather_sums(const PersistParams &P, int par, doub
         s_S[tid] = t;
     }
     __syncthreads();
+    return true;
 }
 
 constexpr int kPersistRegs = 4; // ring words in registers per node: 8 entries, a closed fan of valence <= 7
@@ -2052,7 +2077,6 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
     double *s_red = (double *)(s_rec + 2 * 256);
     double *s_S = s_red + 4 * (kPersistThreads / 64);
     double *s_chunk = s_S + 4;
-    int *s_flag = (int *)(s_chunk + 4 * 32);
     auto t_xy = [&](int s) { return smem + (size_t)(gi + TG * s) * tile_words; };
 
     int32_t node[NPT], hg[NPT], deg[NPT];
@@ -2105,27 +2129,17 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
             hr[lt] = make_double2(-hb.x, -hb.y);
             hp[lt] = make_double2(0.0, 0.0);
         }
-        if ((flags[s] & 20) == 20) store2<true>(P.qx, 2 * P.N, nd, make_double2(0.0, 0.0)); // q_{-1} = 0, parity 0
+        if ((flags[s] & 20) == 20) put_granules(P.qg + 4 * nd, 1u, make_double2(0.0, 0.0)); // q_{-1} = 0, parity 0
     }
     if (blockIdx.x == 0 && tid == 0) acc[1] = 1.0; // "p.q" > 0: alpha finite, multiplies q = 0
     block_sumN<kPersistThreads, 4>(acc, s_red);
     int par = 0;
-    if (tid == 0) {
-        double2 *dst = (double2 *)P.wg_part;
-        store2<true>(dst, 2 * 2 * (int64_t)gridDim.x, 2 * ((int64_t)par * gridDim.x + blockIdx.x), make_double2(acc[0], acc[1]));
-        store2<true>(dst, 2 * 2 * (int64_t)gridDim.x, 2 * ((int64_t)par * gridDim.x + blockIdx.x) + 1,
-                     make_double2(acc[2], acc[3]));
-    }
     unsigned epoch = 1;
-    if (!persist_arrive_wait(P, epoch, s_flag)) return;
-    double2 hq[NPT]; // q of this thread's halo nodes, fetched while the sums are gathered
-    auto fetch_halo_q = [&]() {
-#pragma unroll
-        for (int s = 0; s < NPT; ++s)
-            hq[s] = (flags[s] & 32) ? load2_sc1(P.qx, 2 * P.N, (int64_t)par * P.N + hg[s]) : make_double2(0.0, 0.0);
-    };
-    fetch_halo_q();
-    persist_gather_sums(P, par, s_S, s_rec, s_chunk);
+    if (tid < 2) // the block sums are in every thread: two threads publish the record's two pieces
+        put_granules(P.recg + 4 * (2 * ((int64_t)par * gridDim.x + blockIdx.x) + tid), epoch,
+                     tid == 0 ? make_double2(acc[0], acc[1]) : make_double2(acc[2], acc[3]));
+    double2 hq[NPT]; // q of this thread's halo nodes
+    if (!persist_exchange<NPT>(P, par, epoch, flags, hg, hq, s_S, s_rec, s_chunk)) return;
 
     const double c0 = P.c0, nu = P.nu, h = P.h;
     double target = P.tol, bb = 0.0;
@@ -2204,7 +2218,7 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
             if ((flags[s] & 1) || !(flags[s] & 16)) fx = 0.0;
             if ((flags[s] & 2) || !(flags[s] & 16)) fy = 0.0;
             q[s] = make_double2(fx, fy);
-            if ((flags[s] & 20) == 20) store2<true>(P.qx, 2 * P.N, (int64_t)(par ^ 1) * P.N + node[s], q[s]);
+            if ((flags[s] & 20) == 20) put_granules(P.qg + 4 * ((int64_t)(par ^ 1) * P.N + node[s]), epoch + 1, q[s]);
             acc[0] += r[s].x * r[s].x + r[s].y * r[s].y;
             acc[1] += pa.x * fx + pa.y * fy;
             acc[2] += r[s].x * fx + r[s].y * fy;
@@ -2212,18 +2226,12 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
         }
         block_sumN<kPersistThreads, 4>(acc, s_red);
         par ^= 1;
-        if (tid == 0) {
-            double2 *dst = (double2 *)P.wg_part;
-            store2<true>(dst, 2 * 2 * (int64_t)gridDim.x, 2 * ((int64_t)par * gridDim.x + blockIdx.x),
-                         make_double2(acc[0], acc[1]));
-            store2<true>(dst, 2 * 2 * (int64_t)gridDim.x, 2 * ((int64_t)par * gridDim.x + blockIdx.x) + 1,
-                         make_double2(acc[2], acc[3]));
-        }
         ++epoch;
         ++j;
-        if (!persist_arrive_wait(P, epoch, s_flag)) return;
-        fetch_halo_q();
-        persist_gather_sums(P, par, s_S, s_rec, s_chunk);
+        if (tid < 2)
+            put_granules(P.recg + 4 * (2 * ((int64_t)par * gridDim.x + blockIdx.x) + tid), epoch,
+                         tid == 0 ? make_double2(acc[0], acc[1]) : make_double2(acc[2], acc[3]));
+        if (!persist_exchange<NPT>(P, par, epoch, flags, hg, hq, s_S, s_rec, s_chunk)) return;
     }
     // x of iterate j-1 is in LDS; the verdict is the same in every workgroup
 #pragma unroll

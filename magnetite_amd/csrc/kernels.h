@@ -286,10 +286,9 @@ struct PersistParams {
     const double2 *halo_xy;
     const double2 *bP;
     double2 *x;
-    double2 *qx;       // 2 * N: published q, by parity
-    double *wg_part;   // 2 * grid * 4: dot partials of every workgroup, by parity
-    double *grp_part;  // unused (kept for layout)
-    uint32_t *sync;    // [0..7] arrival counters, [9] timeout word; zeroed before every launch
+    unsigned long long *qg;   // 2 * N * 4 granules {epoch, 32-bit half}: published q, by parity
+    unsigned long long *recg; // 2 * grid * 8 granules: dot partials of every workgroup, by parity
+    uint32_t *sync;           // [9] timeout word; zeroed, like the granules, before every launch
     FusedState *st;
     double *hist;
 };
