@@ -179,8 +179,14 @@ def main():
         Eloc, Nloc = E / world, N / world  # per-GPU share the operator kernel processes per launch
         spmv_bytes = 12.0 * Eloc + 50.0 * Nloc          # matrix-free SpMV
         iter_bytes = 12.0 * Eloc + 242.0 * Nloc         # full CG iteration (SpMV + 2 dots + 3 axpy)
-        fused = args.cg_variant == 1
-        kernel_bytes = iter_bytes if fused else (12.0 * Eloc + 50.0 * Nloc)
+        kind = int(st["cg_kernel"])  # what ran: 2 on-chip single launch, 1 one fused launch per iteration, 0 two launches
+        if kind == 2:
+            # ONE launch runs the whole CG phase (HIP events around it: stats ms_cg): its algorithmic bytes are the
+            # per-iteration figure times the iterations it performed
+            ms_op = st["ms_cg"]
+            kernel_bytes = iter_bytes * iters
+        else:
+            kernel_bytes = iter_bytes if kind == 1 else (12.0 * Eloc + 50.0 * Nloc)
         achieved = kernel_bytes / (ms_op * 1e-3) / 1e9
         # mag_time_spmv applies the plain operator to the WHOLE mesh on every rank (it is not partitioned)
         spmv_bytes = 12.0 * E + 50.0 * N
@@ -190,8 +196,11 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
         if os.path.exists(pmc):  # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md)
             pj = json.load(open(pmc))
-            key = f"{args.workload}:tile{args.tile}:variant{args.cg_variant}"
-            if key in pj:
+            key = f"{args.workload}:tile{args.tile}:kernel{kind}"
+            if key in pj and kind == 2:  # setup + per-iteration traffic, from two PMC runs of different length
+                traffic = pj[key]["hbm_bytes_setup"] + pj[key]["hbm_bytes_per_iteration"] * iters
+                traffic_src = "profiles/r01_pmc_summary.json:" + key
+            elif key in pj:
                 traffic, traffic_src = pj[key]["hbm_bytes_per_launch"], "profiles/r01_pmc_summary.json:" + key
         out = {
             "metric": "elements/sec assembly + CG iters/sec (achieved HBM GB/s), 1M-tri mesh",
@@ -200,17 +209,26 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}, {E} triangles, {N} nodes, left edge fixed, "
                                    f"right edge ux=delta; full solver::run per step; CG stop={args.stop} tol={args.tol:g}",
-                       "elements": E, "nodes": N, "tile_nodes": args.tile, "cg_variant": args.cg_variant, "cg_stop": args.stop, "cg_tol": args.tol,
+                       "elements": E, "nodes": N, "tile_nodes": args.tile, "cg_variant": args.cg_variant, "cg_kernel": kind, "cg_stop": args.stop, "cg_tol": args.tol,
                        "parallelism": f"strips{world}" if world > 1 else "single"},
             "roofline": {"bound": "hbm",
-                         "kernel": ("k_cg_fused_dma<%d> (whole CG iteration in one launch: r,x,p updates + matrix-free "
-                                    "SpMV + 4 dot partials)" % args.tile) if fused else
-                                   ("k_operator_lds<%d> (matrix-free SpMV fused with p and x updates, p.q)" % args.tile),
+                         "kernel": {2: "k_cg_persist<%d> (the whole CG solve in one launch: state resident in registers "
+                                       "and LDS, grid-wide exchange by tagged granules every iteration)" % args.tile,
+                                    1: "k_cg_fused_dma<%d> (whole CG iteration in one launch: r,x,p updates + "
+                                       "matrix-free SpMV + 4 dot partials)" % args.tile,
+                                    0: "k_operator_lds<%d> (matrix-free SpMV fused with p and x updates, p.q)"
+                                       % args.tile}[kind],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "bytes_per_launch": kernel_bytes,
-                         "bytes_formula": "12E+242N (full CG iteration, SURVEY 8d)" if fused else "12E+50N (SpMV, SURVEY 8d)",
-                         "us_per_launch": ms_op * 1e3},
+                         "bytes_formula": {2: "(12E+242N) x iterations (full CG iteration, SURVEY 8d; one launch = one solve)",
+                                           1: "12E+242N (full CG iteration, SURVEY 8d)",
+                                           0: "12E+50N (SpMV, SURVEY 8d)"}[kind],
+                         "us_per_launch": ms_op * 1e3,
+                         "us_per_iteration": st["ms_cg"] * 1e3 / max(iters, 1),
+                         "note": ("the state never leaves the chip: the fraction compares the bytes an unfused "
+                                  "iteration would stream with the time taken, it is not HBM utilisation")
+                                 if kind == 2 else None},
             "spmv": {"kernel": "k_operator_lds<%d,false> (plain matrix-free SpMV)" % args.tile, "achieved": spmv_gbs,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
                      "bytes_per_launch": spmv_bytes, "us_per_launch": ms_spmv * 1e3},

@@ -2003,31 +2003,44 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
 {
     const int tid = threadIdx.x;
     const int grid = gridDim.x;
+    gu32 *tmo = (gu32 *)P.sync + 9;
+    // Phase 1: the records only (one 16-byte piece per thread) -- the cheap sweep that is repeated while other
+    // workgroups are still computing.  Phase 2: q of this thread's halo nodes; their owners stored them before their
+    // record, so this sweep normally succeeds at once (each granule still validates itself).
+    const unsigned long long *rec = P.recg + 4 * (2 * (int64_t)par * grid + tid);
+    const unsigned long long *qbase = P.qg + 4 * (int64_t)par * P.N;
     bool have_rec = tid >= 2 * grid, have_h[NPT];
 #pragma unroll
     for (int s = 0; s < NPT; ++s) {
         have_h[s] = !(flags[s] & 32);
         hq[s] = make_double2(0.0, 0.0);
     }
-    gu32 *tmo = (gu32 *)P.sync + 9;
     bool done = false;
+    int phase = 1;
     for (unsigned spins = 0; spins < P.spin_limit; ++spins) {
         bool ok = true;
-        if (!have_rec) {
-            double2 v;
-            have_rec = get_granules(P.recg + 4 * (2 * (int64_t)par * grid + tid), epoch, v);
-            if (have_rec) s_rec[tid] = v;
-            ok &= have_rec;
-        }
-#pragma unroll
-        for (int s = 0; s < NPT; ++s)
-            if (!have_h[s]) {
-                have_h[s] = get_granules(P.qg + 4 * ((int64_t)par * P.N + hg[s]), epoch, hq[s]);
-                ok &= have_h[s];
+        if (phase == 1) {
+            if (!have_rec) {
+                double2 v;
+                have_rec = get_granules(rec, epoch, v);
+                if (have_rec) s_rec[tid] = v;
             }
+            ok = have_rec;
+        } else {
+#pragma unroll
+            for (int s = 0; s < NPT; ++s)
+                if (!have_h[s]) {
+                    have_h[s] = get_granules(qbase + 4 * (int64_t)hg[s], epoch, hq[s]);
+                    ok &= have_h[s];
+                }
+        }
         if (__syncthreads_and(ok ? 1 : 0)) {
-            done = true;
-            break;
+            if (phase == 2) {
+                done = true;
+                break;
+            }
+            phase = 2;
+            continue;
         }
         if ((spins & 255u) == 255u) { // somebody else gave up: do not wait for a grid that will never be complete
             const int dead =
