@@ -1976,20 +1976,42 @@ __device__ inline void put_granules(unsigned long long *g, unsigned epoch, doubl
                            __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ inline bool get_granules(const unsigned long long *g, unsigned epoch, double2 &v)
+// Four granules (32 bytes) by two 16-byte sc1 loads: each 8-byte granule was written by one atomic store and validates
+// itself, so it does not matter that the pair is not read atomically.  `base` must be wave-uniform (it becomes the
+// buffer resource), the granule group is addressed by the per-lane byte offset.
+__device__ inline bool get_granules(const unsigned long long *base, uint32_t bytes, uint32_t off, unsigned epoch,
+                                    double2 &v)
 {
-    unsigned long long x[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) x[k] = __hip_atomic_load((gu64 *)g + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned w[4];
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        ok &= (unsigned)(x[k] >> 32) == epoch;
-        w[k] = (unsigned)x[k];
-    }
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, (short)0, (int)bytes, 0x00020000);
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 16);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off + 16, 0, 16);
+    const bool ok = a.y == epoch && a.w == epoch && b.y == epoch && b.w == epoch;
+    unsigned w[4] = {a.x, a.z, b.x, b.z};
     __builtin_memcpy(&v, w, 16);
     return ok;
+}
+
+// Sum over the 64 lanes of a wave by DPP (ALU-rate lane moves; __shfl_down goes through the LDS crossbar, ~10x the
+// latency per step, and the on-chip kernel has only two waves per SIMD to hide it).  Inclusive scan inside each row
+// of 16 lanes (row_shr 1, 2, 4, 8), then row 0 -> row 1 and row 2 -> row 3 (row_bcast:15), then lane 31 -> rows 2, 3
+// (row_bcast:31): the total is in lane 63 and comes back in every lane.  A fixed order, like every sum here.
+__device__ inline double wave_sum_dpp(double v)
+{
+#define MAG_DPP_STEP(CTRL, ROWMASK)                                                                                  \
+    {                                                                                                                  \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, false);                   \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, false);                   \
+        v += __hiloint2double(hi, lo);                                                                                 \
+    }
+    MAG_DPP_STEP(0x111, 0xf) // row_shr:1
+    MAG_DPP_STEP(0x112, 0xf) // row_shr:2
+    MAG_DPP_STEP(0x114, 0xf) // row_shr:4
+    MAG_DPP_STEP(0x118, 0xf) // row_shr:8
+    MAG_DPP_STEP(0x142, 0xa) // row_bcast:15 into rows 1 and 3
+    MAG_DPP_STEP(0x143, 0xc) // row_bcast:31 into rows 2 and 3
+#undef MAG_DPP_STEP
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
+                            __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 // Wait for epoch `epoch`: every workgroup's partial record (two 16-byte pieces each, one per thread) and the q of this
@@ -2007,8 +2029,8 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
     // Phase 1: the records only (one 16-byte piece per thread) -- the cheap sweep that is repeated while other
     // workgroups are still computing.  Phase 2: q of this thread's halo nodes; their owners stored them before their
     // record, so this sweep normally succeeds at once (each granule still validates itself).
-    const unsigned long long *rec = P.recg + 4 * (2 * (int64_t)par * grid + tid);
-    const unsigned long long *qbase = P.qg + 4 * (int64_t)par * P.N;
+    const unsigned long long *recb = P.recg + 8 * (int64_t)par * grid; // this parity's records: 64 bytes per workgroup
+    const unsigned long long *qbase = P.qg + 4 * (int64_t)par * P.N;   // ... and q granules: 32 bytes per node
     bool have_rec = tid >= 2 * grid, have_h[NPT];
 #pragma unroll
     for (int s = 0; s < NPT; ++s) {
@@ -2017,12 +2039,14 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
     }
     bool done = false;
     int phase = 1;
+    __builtin_amdgcn_s_sleep(20); // ~0.5 us: the other workgroups' records are still on their way; a sweep that
+    __builtin_amdgcn_s_sleep(20); // comes too early costs a full round trip
     for (unsigned spins = 0; spins < P.spin_limit; ++spins) {
         bool ok = true;
         if (phase == 1) {
             if (!have_rec) {
                 double2 v;
-                have_rec = get_granules(rec, epoch, v);
+                have_rec = get_granules(recb, 64u * (uint32_t)grid, 32u * (uint32_t)tid, epoch, v);
                 if (have_rec) s_rec[tid] = v;
             }
             ok = have_rec;
@@ -2030,7 +2054,7 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
 #pragma unroll
             for (int s = 0; s < NPT; ++s)
                 if (!have_h[s]) {
-                    have_h[s] = get_granules(qbase + 4 * (int64_t)hg[s], epoch, hq[s]);
+                    have_h[s] = get_granules(qbase, 32u * (uint32_t)P.N, 32u * (uint32_t)hg[s], epoch, hq[s]);
                     ok &= have_h[s];
                 }
         }
@@ -2053,26 +2077,49 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
         if (tid == 0) __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return false;
     }
-    if (tid < 4 * 32) {
-        const int c = tid & 3, k = tid >> 2;
-        const double *rec = (const double *)s_rec;
-        double t = 0.0;
-        const int end = 8 * k + 8 < grid ? 8 * k + 8 : grid;
-        for (int m = 8 * k; m < end; ++m) t += rec[4 * m + c];
-        s_chunk[4 * k + c] = t;
-    }
-    __syncthreads();
-    if (tid < 4) {
-        double t = 0.0;
-        const int nchunks = (grid + 7) / 8;
-        for (int k = 0; k < nchunks; ++k) t += s_chunk[4 * k + tid];
-        s_S[tid] = t;
+    // every workgroup sums the same values in the same order (four records per lane, then the lanes): same bits
+    // everywhere
+    __syncthreads(); // s_rec complete
+    if (tid < 64) {
+        double S[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int m = tid; m < grid; m += 64) {
+            const double2 a = s_rec[2 * m], b = s_rec[2 * m + 1];
+            S[0] += a.x;
+            S[1] += a.y;
+            S[2] += b.x;
+            S[3] += b.y;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) S[c] = wave_sum_dpp(S[c]);
+        if (tid < 4) s_S[tid] = tid == 0 ? S[0] : (tid == 1 ? S[1] : (tid == 2 ? S[2] : S[3]));
     }
     __syncthreads();
     return true;
 }
 
-constexpr int kPersistRegs = 4; // ring words in registers per node: 8 entries, a closed fan of valence <= 7
+// Workgroup totals of four partial sums for the two publishing threads (0 and 1): DPP wave trees, then the eight
+// waves in order.
+__device__ inline void persist_block_sum(double (&acc)[4], double *s_red)
+{
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = wave_sum_dpp(acc[c]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s_red[c * (kPersistThreads / 64) + (threadIdx.x >> 6)] = acc[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < kPersistThreads / 64; ++i) t += s_red[c * (kPersistThreads / 64) + i];
+            acc[c] = t;
+        }
+    }
+}
+
+constexpr int kPersistRegs = 5; // ring words in registers per node: 10 entries, a closed fan of valence <= 9
 constexpr int kPersistNpt = 4;  // nodes (tiles) per thread
 
 template <int B>
@@ -2145,7 +2192,7 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
         if ((flags[s] & 20) == 20) put_granules(P.qg + 4 * nd, 1u, make_double2(0.0, 0.0)); // q_{-1} = 0, parity 0
     }
     if (blockIdx.x == 0 && tid == 0) acc[1] = 1.0; // "p.q" > 0: alpha finite, multiplies q = 0
-    block_sumN<kPersistThreads, 4>(acc, s_red);
+    persist_block_sum(acc, s_red);
     int par = 0;
     unsigned epoch = 1;
     if (tid < 2) // the block sums are in every thread: two threads publish the record's two pieces
@@ -2237,7 +2284,7 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
             acc[2] += r[s].x * fx + r[s].y * fy;
             acc[3] += fx * fx + fy * fy;
         }
-        block_sumN<kPersistThreads, 4>(acc, s_red);
+        persist_block_sum(acc, s_red);
         par ^= 1;
         ++epoch;
         ++j;
