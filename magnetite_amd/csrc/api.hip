@@ -384,7 +384,7 @@ int ensure_order(mag_ctx *ctx)
     // on-chip CG: every tile resident at once (one workgroup per CU, kPersistNpt * 512 / B tiles each)
     ctx->persist = false;
     if (ctx->opt.cg_variant == 2 && ctx->use_lds && !ctx->dist && !ctx->persist_failed && ctx->opt.precision == 0 &&
-        ctx->opt.preconditioner == 0 && ctx->opt.cg_operator == MAG_OP_MATRIX_FREE && max_halo <= B) {
+        ctx->opt.preconditioner == 0 && ctx->opt.cg_operator == MAG_OP_MATRIX_FREE) {
         int dev = 0, cus = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -396,6 +396,7 @@ int ensure_order(mag_ctx *ctx)
         if (const char *e = getenv("MAG_TUNE_PERSIST_MIN_K")) kmin = atoi(e);
         ctx->persist_maxh = ((max_halo + 3) / 4) * 4;
         if (kmax > 0 && k >= 1 && k >= kmin && k <= kmax && (T + k - 1) / k <= 256 && // the gather holds 256 records
+            (int64_t)k * max_halo <= 2 * 512 && // a workgroup's halo entries are dealt out two per thread
             magk::persist_lds_bytes(B, ctx->cap, ctx->persist_maxh) <= 160 * 1024) {
             ctx->persist = true;
             ctx->persist_k = k;

@@ -2018,10 +2018,9 @@ __device__ inline double wave_sum_dpp(double v)
 // thread's halo nodes, swept together until every tag matches; then the records are summed in one fixed two-level
 // order (chunks of eight workgroups, then the chunks) so that all workgroups hold the same bits.  grid <= 256.
 // Returns false when the spin budget runs out (some workgroup is not running): the timeout word is set for the host.
-template <int NPT>
-__device__ inline bool persist_exchange(const PersistParams &P, int par, unsigned epoch, const uint32_t (&flags)[NPT],
-                                        const int32_t (&hg)[NPT], double2 (&hq)[NPT], double *s_S, double2 *s_rec,
-                                        double *s_chunk)
+template <int NH>
+__device__ inline bool persist_exchange(const PersistParams &P, int par, unsigned epoch, const int32_t (&hg)[NH],
+                                        double2 (&hq)[NH], double *s_S, double2 *s_rec, double *s_chunk)
 {
     const int tid = threadIdx.x;
     const int grid = gridDim.x;
@@ -2030,10 +2029,10 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
     // thread's halo nodes.
     const unsigned long long *recb = P.recg + 8 * (int64_t)par * grid; // this parity's records: 64 bytes per workgroup
     const unsigned long long *qbase = P.qg + 4 * (int64_t)par * P.N;   // ... and q granules: 32 bytes per node
-    bool have_rec = tid >= 2 * grid, have_h[NPT];
+    bool have_rec = tid >= 2 * grid, have_h[NH];
 #pragma unroll
-    for (int s = 0; s < NPT; ++s) {
-        have_h[s] = !(flags[s] & 32);
+    for (int s = 0; s < NH; ++s) {
+        have_h[s] = hg[s] < 0;
         hq[s] = make_double2(0.0, 0.0);
     }
     bool done = false;
@@ -2049,7 +2048,7 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
             ok = have_rec;
         }
 #pragma unroll
-        for (int s = 0; s < NPT; ++s)
+        for (int s = 0; s < NH; ++s)
             if (!have_h[s]) {
                 have_h[s] = get_granules(qbase, 32u * (uint32_t)P.N, 32u * (uint32_t)hg[s], epoch, hq[s]);
                 ok &= have_h[s];
@@ -2113,6 +2112,7 @@ __device__ inline void persist_block_sum(double (&acc)[4], double *s_red)
 
 constexpr int kPersistRegs = 5; // ring words in registers per node: 10 entries, a closed fan of valence <= 9
 constexpr int kPersistNpt = 4;  // nodes (tiles) per thread
+constexpr int kPersistNh = 2;   // halo entries per thread: a workgroup's tiles may carry 1024 halo nodes in all
 
 template <int B>
 __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistParams P)
@@ -2131,8 +2131,10 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
     double *s_chunk = s_S + 4;
     auto t_xy = [&](int s) { return smem + (size_t)(gi + TG * s) * tile_words; };
 
-    int32_t node[NPT], hg[NPT], deg[NPT];
-    uint32_t flags[NPT]; // bit 0/1 prescribed ux/uy, 2 published, 3 live tile, 4 valid node, 5 halo lane
+    constexpr int NH = kPersistNh; // halo entries per thread: the workgroup's halo nodes are dealt out over ALL threads
+    int32_t node[NPT], deg[NPT];
+    int32_t hg[NH], hloc[NH]; // global id (-1: none) and LDS position (tile * tile_words-relative) of a halo entry
+    uint32_t flags[NPT]; // bit 0/1 prescribed ux/uy, 2 published, 3 live tile, 4 valid node
     uint32_t w[NPT][kPersistRegs];
     int64_t ell_off[NPT];
     double2 r[NPT], q[NPT];
@@ -2144,7 +2146,6 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
         const int32_t t = blockIdx.x * P.tiles_per_wg + l;
         double2 *xy = t_xy(s), *pim = xy + cap, *hr = pim + cap, *hp = hr + maxh, *xs = hp + maxh;
         node[s] = 0;
-        hg[s] = 0;
         deg[s] = 0;
         flags[s] = 3;
         ell_off[s] = 0;
@@ -2173,15 +2174,31 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
 #pragma unroll
         for (int k = 0; k < kPersistRegs; ++k)
             if (k < deg[s]) w[s][k] = P.ell16[ell_off[s] + (int64_t)k * B];
-        if (lt < tm.nh) {
-            flags[s] |= 32;
-            hg[s] = P.halo_g[tm.hoff + lt];
-            xy[B + lt] = P.halo_xy[tm.hoff + lt];
-            const double2 hb = P.bP[hg[s]];
-            hr[lt] = make_double2(-hb.x, -hb.y);
-            hp[lt] = make_double2(0.0, 0.0);
-        }
         if ((flags[s] & 20) == 20) put_granules(P.qg + 4 * nd, 1u, make_double2(0.0, 0.0)); // q_{-1} = 0, parity 0
+    }
+    // halo entries of the workgroup's tiles, in tile order, dealt out round-robin: thread t takes entries t, t + 512
+    {
+        const int32_t t_first = blockIdx.x * P.tiles_per_wg;
+#pragma unroll
+        for (int e = 0; e < NH; ++e) {
+            hg[e] = -1;
+            hloc[e] = 0;
+            int32_t rem = tid + kPersistThreads * e;
+            for (int l = 0; l < P.tiles_per_wg && t_first + l < P.T; ++l) {
+                const TileMeta tm = P.meta[t_first + l];
+                if (rem < tm.nh) {
+                    double2 *xy = smem + (size_t)l * tile_words;
+                    hg[e] = P.halo_g[tm.hoff + rem];
+                    hloc[e] = l * tile_words + rem;
+                    xy[B + rem] = P.halo_xy[tm.hoff + rem];
+                    const double2 hb = P.bP[hg[e]];
+                    xy[2 * cap + rem] = make_double2(-hb.x, -hb.y);      // halo r
+                    xy[2 * cap + maxh + rem] = make_double2(0.0, 0.0); // halo p
+                    break;
+                }
+                rem -= tm.nh;
+            }
+        }
     }
     if (blockIdx.x == 0 && tid == 0) acc[1] = 1.0; // "p.q" > 0: alpha finite, multiplies q = 0
     persist_block_sum(acc, s_red);
@@ -2190,8 +2207,8 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
     if (tid < 2) // the block sums are in every thread: two threads publish the record's two pieces
         put_granules(P.recg + 4 * (2 * ((int64_t)par * gridDim.x + blockIdx.x) + tid), epoch,
                      tid == 0 ? make_double2(acc[0], acc[1]) : make_double2(acc[2], acc[3]));
-    double2 hq[NPT]; // q of this thread's halo nodes
-    if (!persist_exchange<NPT>(P, par, epoch, flags, hg, hq, s_S, s_rec, s_chunk)) return;
+    double2 hq[NH]; // q of this thread's halo nodes
+    if (!persist_exchange<NH>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk)) return;
 
     const double c0 = P.c0, nu = P.nu, h = P.h;
     double target = P.tol, bb = 0.0;
@@ -2235,17 +2252,20 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
             pn.x = -r[s].x + beta * po.x;
             pn.y = -r[s].y + beta * po.y;
             pim[lt] = pn;
-            if (flags[s] & 32) {
-                double2 hrv = hr[lt], hpv = hp[lt];
-                hrv.x += alpha * hq[s].x;
-                hrv.y += alpha * hq[s].y;
+        }
+#pragma unroll
+        for (int e = 0; e < NH; ++e)
+            if (hg[e] >= 0) {
+                double2 *hbase = smem + hloc[e]; // = tile base + position: coordinates at [B], p image at [cap + B], ...
+                double2 hrv = hbase[2 * cap], hpv = hbase[2 * cap + maxh];
+                hrv.x += alpha * hq[e].x;
+                hrv.y += alpha * hq[e].y;
                 hpv.x = -hrv.x + beta * hpv.x;
                 hpv.y = -hrv.y + beta * hpv.y;
-                hr[lt] = hrv;
-                hp[lt] = hpv;
-                pim[B + lt] = hpv;
+                hbase[2 * cap] = hrv;
+                hbase[2 * cap + maxh] = hpv;
+                hbase[cap + B] = hpv;
             }
-        }
         __syncthreads();
 
         // ---- q = M K M p on the owned nodes, dot partials, publication
@@ -2283,7 +2303,7 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
         if (tid < 2)
             put_granules(P.recg + 4 * (2 * ((int64_t)par * gridDim.x + blockIdx.x) + tid), epoch,
                          tid == 0 ? make_double2(acc[0], acc[1]) : make_double2(acc[2], acc[3]));
-        if (!persist_exchange<NPT>(P, par, epoch, flags, hg, hq, s_S, s_rec, s_chunk)) return;
+        if (!persist_exchange<NH>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk)) return;
     }
     // x of iterate j-1 is in LDS; the verdict is the same in every workgroup
 #pragma unroll
