@@ -166,8 +166,8 @@ def main():
         elapsed = float(t.item())
 
     st = ctx.stats()
-    if args.tile == 0:
-        args.tile = 512 if N >= 512 * 512 else 256  # what the library chose (mag_options.tile_nodes = 0)
+    if args.tile == 0:  # what the library chose (mag_options.tile_nodes = 0): the tile size that gives its tile count
+        args.tile = next(b for b in (256, 512, 1024) if (N + b - 1) // b == int(st["num_tiles"]))
     # HIP events on the library's own stream around op_reps back-to-back launches (mag_time_operator / mag_time_spmv)
     ms_op = ctx.time_operator(args.op_reps)   # the CG iteration kernel (dominant: one launch per iteration)
     ms_spmv = ctx.time_spmv(args.op_reps)     # the plain matrix-free SpMV y = M K M v

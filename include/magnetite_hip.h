@@ -83,8 +83,9 @@ typedef struct mag_options {
                              the RHS and reactions from its rows; 0: matrix-free everywhere */
     int32_t check_every;  /* CG iterations per host convergence poll (default 64, even)    */
     int32_t use_graph;    /* 1 (default): replay the CG iteration block as a hipGraph      */
-    int32_t tile_nodes;   /* owned nodes per workgroup tile: 256 | 512 | 1024; 0 (default): 512 for meshes
-                             of >= 262144 nodes, else 256                                  */
+    int32_t tile_nodes;   /* owned nodes per workgroup tile: 256 | 512 | 1024; 0 (default): 512 for meshes of
+                             >= 262144 nodes and for meshes of 32768..524288 nodes the on-chip CG can hold
+                             (cg_variant 2), else 256                                       */
     int32_t history_len;  /* keep the cost of the first history_len iterations (tests)     */
     int32_t verbose;      /* 1: print the reference's "info:" phase lines to stdout        */
     int32_t op_variant;   /* 0 (default): LDS-halo operator when every tile fits LDS, else the

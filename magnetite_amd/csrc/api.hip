@@ -212,7 +212,14 @@ int ensure_order(mag_ctx *ctx)
     // automatic tile size: 512-node tiles once the mesh has at least as many of them as the fused kernel keeps
     // resident (2 per CU x 256 CUs); smaller meshes are latency-bound and run faster on twice as many 256-node tiles
     // (measured: 100k triangles 6.6 vs 7.7 us per iteration; 1M triangles 22.0 vs 20.4)
-    if (ctx->opt.tile_nodes == 0) ctx->B = (N >= 512 * 512) ? 512 : 256;
+    // (since the on-chip CG exists, 512-node tiles also win on mid-size meshes it can hold: 6.2 / 6.4 / 8.3 us per
+    // iteration at 59k / 121k / 245k nodes against 6.9 / 8.8 / 13.8 with streamed 256-node tiles)
+    const bool on_chip_candidate = ctx->opt.cg_variant == 2 && ctx->comm.nranks == 1 &&
+                                   getenv("MAG_TUNE_FORCE_DIST") == nullptr && ctx->opt.precision == 0 &&
+                                   ctx->opt.preconditioner == 0 && ctx->opt.cg_operator == MAG_OP_MATRIX_FREE &&
+                                   ctx->opt.op_variant != 1 && !ctx->persist_failed;
+    if (ctx->opt.tile_nodes == 0)
+        ctx->B = (N >= 512 * 512 || (on_chip_candidate && N >= 32768 && N <= 1024 * 512)) ? 512 : 256;
     const int32_t B = ctx->B;
     const int32_t T = (int32_t)((N + B - 1) / B);
     ctx->T = T;
@@ -390,9 +397,10 @@ int ensure_order(mag_ctx *ctx)
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const int kmax = magk::persist_tiles_per_wg(B);
         const int k = cus > 0 ? (T + cus - 1) / cus : 0;
-        // Below three tiles per workgroup the grid barrier (~8 us) costs more than re-streaming the state does
-        // (measured crossover at ~700 tiles of 512 nodes); tests lower the bar to reach the kernel with small meshes.
-        int kmin = 3;
+        // Measured against the streaming kernel on the same 512-node tiles the on-chip kernel wins from one tile per
+        // workgroup up (6.2 vs 7.9 us per iteration at 115 tiles, 12.6 vs 20.3 at 982); with 256-node tiles it does not
+        // (and eight of them rarely fit the LDS), so those only run it when a test asks (MAG_TUNE_PERSIST_MIN_K=1).
+        int kmin = B == 512 ? 1 : 9;
         if (const char *e = getenv("MAG_TUNE_PERSIST_MIN_K")) kmin = atoi(e);
         ctx->persist_maxh = ((max_halo + 3) / 4) * 4;
         if (kmax > 0 && k >= 1 && k >= kmin && k <= kmax && (T + k - 1) / k <= 256 && // the gather holds 256 records
