@@ -114,7 +114,11 @@ struct mag_ctx {
     // on-chip CG (cg.hip, k_cg_persist): the whole solve in one launch when every tile fits registers + LDS
     bool persist = false, persist_failed = false;
     int32_t persist_k = 0, persist_grid = 0, persist_maxh = 0, cg_kernel = 0;
-    DevBuf qx, wg_part, psync; // published-q granules, partial-record granules, timeout word
+    DevBuf qx, wg_part, psync, grec; // published-q granules, partial-record granules, timeout word, republished sums
+    // multi-GPU on-chip CG: a window of host memory mapped by every rank (mag_comm_set_window)
+    void *win_host = nullptr, *win_dev = nullptr;
+    size_t win_bytes = 0;
+    uint32_t solve_seq = 0;
     int nsums() const { return pre ? 5 : 4; }
     DevBuf xy32, hxy32, rqp32a, rqp32b, x32; // fp32 leg (mag_options.precision = 1)
     hipGraphExec_t graph = nullptr;
@@ -214,12 +218,13 @@ int ensure_order(mag_ctx *ctx)
     // (measured: 100k triangles 6.6 vs 7.7 us per iteration; 1M triangles 22.0 vs 20.4)
     // (since the on-chip CG exists, 512-node tiles also win on mid-size meshes it can hold: 6.2 / 6.4 / 8.3 us per
     // iteration at 59k / 121k / 245k nodes against 6.9 / 8.8 / 13.8 with streamed 256-node tiles)
-    const bool on_chip_candidate = ctx->opt.cg_variant == 2 && ctx->comm.nranks == 1 &&
+    const bool on_chip_candidate = ctx->opt.cg_variant == 2 && (ctx->comm.nranks == 1 || ctx->win_dev != nullptr) &&
                                    getenv("MAG_TUNE_FORCE_DIST") == nullptr && ctx->opt.precision == 0 &&
                                    ctx->opt.preconditioner == 0 && ctx->opt.cg_operator == MAG_OP_MATRIX_FREE &&
                                    ctx->opt.op_variant != 1 && !ctx->persist_failed;
     if (ctx->opt.tile_nodes == 0)
-        ctx->B = (N >= 512 * 512 || (on_chip_candidate && N >= 32768 && N <= 1024 * 512)) ? 512 : 256;
+        ctx->B = (N >= 512 * 512 || (on_chip_candidate && N >= 32768 && N <= (int64_t)ctx->comm.nranks * 1024 * 512))
+                     ? 512 : 256;
     const int32_t B = ctx->B;
     const int32_t T = (int32_t)((N + B - 1) / B);
     ctx->T = T;
@@ -388,27 +393,34 @@ int ensure_order(mag_ctx *ctx)
                        ctx->ell.as<int2>(), s);
     }
     HIPCHK(hipGetLastError());
-    // on-chip CG: every tile resident at once (one workgroup per CU, kPersistNpt * 512 / B tiles each)
+    // on-chip CG: every tile resident at once (one workgroup per CU, kPersistNpt * 512 / B tiles each).  With several
+    // ranks the decision uses only quantities every rank computes identically (the largest tile count of a rank, the
+    // global halo bound, the window size), so all ranks take the same path.
     ctx->persist = false;
-    if (ctx->opt.cg_variant == 2 && ctx->use_lds && !ctx->dist && !ctx->persist_failed && ctx->opt.precision == 0 &&
-        ctx->opt.preconditioner == 0 && ctx->opt.cg_operator == MAG_OP_MATRIX_FREE) {
+    const int R = ctx->comm.nranks;
+    const bool mg = R > 1;
+    const bool forced_dist = ctx->dist && !mg; // single-rank rehearsal of the distributed protocol: streaming kernels
+    if (ctx->opt.cg_variant == 2 && ctx->use_lds && !forced_dist && !ctx->persist_failed && ctx->opt.precision == 0 &&
+        ctx->opt.preconditioner == 0 && ctx->opt.cg_operator == MAG_OP_MATRIX_FREE &&
+        (!mg || (ctx->win_dev != nullptr && ctx->win_bytes >= 64 + 128 * (size_t)R + 64 * (size_t)ctx->n_iface))) {
         int dev = 0, cus = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const int kmax = magk::persist_tiles_per_wg(B);
-        const int k = cus > 0 ? (T + cus - 1) / cus : 0;
+        const int32_t tiles_max = (T + R - 1) / R; // the most tiles any rank runs
+        const int k = cus > 0 ? (tiles_max + cus - 1) / cus : 0;
         // Measured against the streaming kernel on the same 512-node tiles the on-chip kernel wins from one tile per
         // workgroup up (6.2 vs 7.9 us per iteration at 115 tiles, 12.6 vs 20.3 at 982); with 256-node tiles it does not
         // (and eight of them rarely fit the LDS), so those only run it when a test asks (MAG_TUNE_PERSIST_MIN_K=1).
         int kmin = B == 512 ? 1 : 9;
         if (const char *e = getenv("MAG_TUNE_PERSIST_MIN_K")) kmin = atoi(e);
         ctx->persist_maxh = ((max_halo + 3) / 4) * 4;
-        if (kmax > 0 && k >= 1 && k >= kmin && k <= kmax && (T + k - 1) / k <= 256 && // the gather holds 256 records
+        if (kmax > 0 && k >= 1 && k >= kmin && k <= kmax && (tiles_max + k - 1) / k <= 256 && // the gather holds 256
             (int64_t)k * max_halo <= 2 * 512 && // a workgroup's halo entries are dealt out two per thread
             magk::persist_lds_bytes(B, ctx->cap, ctx->persist_maxh) <= 160 * 1024) {
             ctx->persist = true;
             ctx->persist_k = k;
-            ctx->persist_grid = (T + k - 1) / k;
+            ctx->persist_grid = (ctx->t1 - ctx->t0 + k - 1) / k;
         }
     }
     ctx->have_order = true;
@@ -955,7 +967,36 @@ int cg_phase_persist(mag_ctx *ctx)
     HIPCHK(hipMemsetAsync(ctx->wg_part.p, 0, rec_bytes, s));
     HIPCHK(hipMemsetAsync(ctx->psync.p, 0, 64, s));
     HIPCHK(hipMemsetAsync(ctx->fstate.p, 0, sizeof(FusedState), s));
+    const int R = ctx->comm.nranks;
+    const bool mg = R > 1;
     magk::PersistParams P = {};
+    P.nranks = 1;
+    if (mg) {
+        // interface slot tables (as the streaming multi-GPU path uses them), the republished-sums record, the window
+        HIPCHK(ctx->own_qslot.reserve(4 * (size_t)ctx->N));
+        HIPCHK(ctx->halo_qslot.reserve(4 * (size_t)std::max<int64_t>(ctx->halo_total, 1)));
+        magk::comm_slots(ctx->iface.as<int32_t>(), ctx->n_iface, ctx->own0, ctx->own1, ctx->halo_g.as<int32_t>(),
+                         ctx->halo_total, ctx->N, ctx->own_qslot.as<int32_t>(), ctx->halo_qslot.as<int32_t>(), s);
+        HIPCHK(ctx->grec.reserve(2 * 64));
+        HIPCHK(hipMemsetAsync(ctx->grec.p, 0, 2 * 64, s));
+        // The window is never zeroed: tags carry the solve's sequence number (same on every rank: all ranks run the
+        // same solves), so nothing of an earlier solve can look current.  4096 solves share 12 bits.
+        ctx->solve_seq = (ctx->solve_seq + 1) & 0xfffu;
+        if (ctx->solve_seq == 0) ctx->solve_seq = 1;
+        uint8_t *w = (uint8_t *)ctx->win_dev;
+        P.t0 = ctx->t0;
+        P.t1 = ctx->t1;
+        P.rank = ctx->comm.rank;
+        P.nranks = R;
+        P.n_iface = ctx->n_iface;
+        P.tag_base = ctx->solve_seq << 20;
+        P.own_qslot = ctx->own_qslot.as<int32_t>();
+        P.halo_qslot = ctx->halo_qslot.as<int32_t>();
+        P.win_tmo = (uint32_t *)w;
+        P.win_rec = (unsigned long long *)(w + 64);
+        P.win_q = (unsigned long long *)(w + 64 + 128 * (size_t)R);
+        P.grec = ctx->grec.as<unsigned long long>();
+    }
     P.N = ctx->N;
     P.T = ctx->T;
     P.tiles_per_wg = ctx->persist_k;
@@ -984,6 +1025,13 @@ int cg_phase_persist(mag_ctx *ctx)
     P.sync = ctx->psync.as<uint32_t>();
     P.st = ctx->fstate.as<FusedState>();
     P.hist = ctx->hist.as<double>();
+    if (mg) {
+        // every rank's kernel must be running before anybody's spin budget runs out: line the streams up first
+        P.spin_limit = 1u << 21;
+        std::string msg;
+        HIPCHK(hipMemsetAsync(ctx->comm_pq.p, 0, 8, s));
+        if (int rc = ctx->comm.allreduce_sum(ctx->comm_pq.as<double>(), 1, s, msg)) return fail(ctx, rc, "%s", msg.c_str());
+    }
     magk::persist_launch(P, ctx->B, grid, s);
     HIPCHK(hipGetLastError());
     uint32_t h_sync[16] = {};
@@ -991,7 +1039,18 @@ int cg_phase_persist(mag_ctx *ctx)
     HIPCHK(hipMemcpyAsync(h_sync, ctx->psync.p, 64, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const FusedState &st = ctx->h_fstate[2];
-    if (h_sync[9] != 0 || !st.done) {
+    bool failed = h_sync[9] != 0 || !st.done;
+    if (mg) { // all ranks must agree before anyone changes path: sum of the failure flags
+        double flag = failed ? 1.0 : 0.0;
+        std::string msg;
+        HIPCHK(hipMemcpyAsync(ctx->comm_pq.p, &flag, 8, hipMemcpyHostToDevice, s));
+        if (int rc = ctx->comm.allreduce_sum(ctx->comm_pq.as<double>(), 1, s, msg)) return fail(ctx, rc, "%s", msg.c_str());
+        HIPCHK(hipMemcpyAsync(&flag, ctx->comm_pq.p, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        failed = flag != 0.0;
+        if (failed) *(volatile uint32_t *)ctx->win_host = 0; // the window's timeout word, for the next context
+    }
+    if (failed) {
         // a workgroup gave up waiting at the grid barrier (not every workgroup resident: the GPU is shared with
         // another process, or fewer CUs are usable than reported): use the streaming kernels from now on
         ctx->persist_failed = true;
@@ -1001,6 +1060,13 @@ int cg_phase_persist(mag_ctx *ctx)
         return cg_phase_fused(ctx);
     }
     ctx->cg_kernel = 2;
+    if (mg) { // every rank returns the whole solution: owned entries summed over ranks, as on the streaming path
+        magk::zero_unowned(ctx->x.as<double2>(), ctx->N, ctx->own0, ctx->own1, s);
+        std::string msg;
+        if (int rc = ctx->comm.allreduce_sum(ctx->x.as<double>(), 2 * ctx->N, s, msg))
+            return fail(ctx, rc, "%s", msg.c_str());
+        HIPCHK(hipStreamSynchronize(s));
+    }
     ctx->stats.iterations = st.iterations;
     ctx->stats.final_cost = st.final_cost;
     ctx->stats.rhs_norm = std::sqrt(st.bb);
@@ -1274,6 +1340,7 @@ void mag_destroy(mag_ctx *ctx)
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
         ctx->comm.destroy();
+        if (ctx->win_host) (void)hipHostUnregister(ctx->win_host);
         if (ctx->graph) (void)hipGraphExecDestroy(ctx->graph);
         if (ctx->h_state) (void)hipHostFree(ctx->h_state);
         if (ctx->h_fstate) (void)hipHostFree(ctx->h_fstate);
@@ -1672,6 +1739,29 @@ int mag_comm_init_rccl(mag_ctx *ctx, const void *unique_id, int32_t nranks, int3
     std::string msg;
     const int rc = ctx->comm.init_rccl(unique_id, nranks, rank, ctx->stream, msg);
     if (rc) return fail(ctx, rc, "%s", msg.c_str());
+    return MAG_OK;
+}
+
+int mag_comm_set_window(mag_ctx *ctx, void *host_ptr, uint64_t bytes)
+{
+    if (int rc = enter(ctx)) return rc;
+    if (ctx->win_host) {
+        (void)hipHostUnregister(ctx->win_host);
+        ctx->win_host = ctx->win_dev = nullptr;
+        ctx->win_bytes = 0;
+    }
+    if (!host_ptr || bytes == 0) return MAG_OK; // window removed
+    if (bytes < 4096) return fail(ctx, MAG_ERR_BAD_ARGS, "window of %llu bytes is too small", (unsigned long long)bytes);
+    HIPCHK(hipHostRegister(host_ptr, (size_t)bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+    void *dev = nullptr;
+    const hipError_t e = hipHostGetDevicePointer(&dev, host_ptr, 0);
+    if (e != hipSuccess) {
+        (void)hipHostUnregister(host_ptr);
+        return fail(ctx, MAG_ERR_HIP, "hipHostGetDevicePointer failed: %s", hipGetErrorString(e));
+    }
+    ctx->win_host = host_ptr;
+    ctx->win_dev = dev;
+    ctx->win_bytes = (size_t)bytes;
     return MAG_OK;
 }
 

@@ -2088,6 +2088,172 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
     return true;
 }
 
+// ---- multi-GPU: the same granules through a window of HOST memory every rank has mapped (system scope) ----
+__device__ inline void put_granules_sys(unsigned long long *g, unsigned tag, double2 v)
+{
+    unsigned w[4];
+    __builtin_memcpy(w, &v, 16);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        __hip_atomic_store((gu64 *)g + k, ((unsigned long long)tag << 32) | w[k], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__device__ inline bool get_granules_sys(const unsigned long long *g, unsigned tag, double2 &v)
+{
+    unsigned long long x[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) x[k] = __hip_atomic_load((gu64 *)g + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    unsigned w[4];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ok &= (unsigned)(x[k] >> 32) == tag;
+        w[k] = (unsigned)x[k];
+    }
+    __builtin_memcpy(&v, w, 16);
+    return ok;
+}
+
+// Exchange of the multi-GPU kernel.  Halo q: from this GPU's granules, or from the window when another rank owns the
+// node (hg < 0 encodes the interface slot as -2 - slot).  Sums: workgroup 0 gathers this rank's records, publishes
+// their sum in the window, gathers every rank's record there, sums them in rank order and republishes the result on
+// the device; all other workgroups wait for that republished record.  Every workgroup on every rank ends with the
+// same bits.
+template <int NH>
+__device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsigned tag, const int32_t (&hg)[NH],
+                                           double2 (&hq)[NH], double *s_S, double2 *s_rec)
+{
+    const int tid = threadIdx.x;
+    const int grid = gridDim.x, R = P.nranks;
+    gu32 *tmo = (gu32 *)P.sync + 9;
+    gu32 *wtmo = (gu32 *)P.win_tmo;
+    const unsigned long long *recb = P.recg + 8 * (int64_t)par * grid;
+    const unsigned long long *qbase = P.qg + 4 * (int64_t)par * P.N;
+    const unsigned long long *wq = P.win_q + 4 * (int64_t)par * P.n_iface;
+    const bool lead = blockIdx.x == 0;
+    bool have_h[NH];
+#pragma unroll
+    for (int e = 0; e < NH; ++e) {
+        have_h[e] = hg[e] == -1;
+        hq[e] = make_double2(0.0, 0.0);
+    }
+    auto gave_up = [&](unsigned spins) { // uniform: every 256th spin one lane looks at the two timeout words
+        if ((spins & 255u) != 255u) return false;
+        const int dead = tid == 0 && (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                                      __hip_atomic_load(wtmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
+                             ? 1 : 0;
+        return __syncthreads_or(dead) != 0;
+    };
+    auto fail = [&]() {
+        if (tid == 0) {
+            __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(wtmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return false;
+    };
+    auto fetch_halo = [&](bool &ok) {
+#pragma unroll
+        for (int e = 0; e < NH; ++e)
+            if (!have_h[e]) {
+                have_h[e] = hg[e] >= 0 ? get_granules(qbase, 32u * (uint32_t)P.N, 32u * (uint32_t)hg[e], tag, hq[e])
+                                       : get_granules_sys(wq + 4 * (int64_t)(-2 - hg[e]), tag, hq[e]);
+                ok &= have_h[e];
+            }
+    };
+    __builtin_amdgcn_s_sleep(20);
+    __builtin_amdgcn_s_sleep(20);
+    if (lead) {
+        // (1) this rank's records (and this workgroup's own halo values)
+        bool have_rec = tid >= 2 * grid, done = false;
+        unsigned spins = 0;
+        for (; spins < P.spin_limit; ++spins) {
+            bool ok = true;
+            if (!have_rec) {
+                double2 v;
+                have_rec = get_granules(recb, 64u * (uint32_t)grid, 32u * (uint32_t)tid, tag, v);
+                if (have_rec) s_rec[tid] = v;
+                ok = have_rec;
+            }
+            fetch_halo(ok);
+            if (__syncthreads_and(ok ? 1 : 0)) {
+                done = true;
+                break;
+            }
+            if (gave_up(spins)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!done) return fail();
+        if (tid < 64) {
+            double S[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int m = tid; m < grid; m += 64) {
+                const double2 a = s_rec[2 * m], b = s_rec[2 * m + 1];
+                S[0] += a.x;
+                S[1] += a.y;
+                S[2] += b.x;
+                S[3] += b.y;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) S[c] = wave_sum_dpp(S[c]);
+            // (2) this rank's sums into the window
+            if (tid < 2)
+                put_granules_sys(P.win_rec + 4 * (2 * ((int64_t)par * R + P.rank) + tid), tag,
+                                 tid == 0 ? make_double2(S[0], S[1]) : make_double2(S[2], S[3]));
+        }
+        __syncthreads();
+        // (3) every rank's sums from the window
+        bool have_w = tid >= 2 * R;
+        done = false;
+        for (; spins < P.spin_limit; ++spins) {
+            if (!have_w) {
+                double2 v;
+                have_w = get_granules_sys(P.win_rec + 4 * (2 * (int64_t)par * R + tid), tag, v);
+                if (have_w) s_rec[tid] = v;
+            }
+            if (__syncthreads_and(have_w ? 1 : 0)) {
+                done = true;
+                break;
+            }
+            if (gave_up(spins)) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (!done) return fail();
+        if (tid < 4) { // rank order: the same bits on every rank
+            const double *rec = (const double *)s_rec;
+            double t = 0.0;
+            for (int r = 0; r < R; ++r) t += rec[4 * r + tid];
+            s_S[tid] = t;
+        }
+        __syncthreads();
+        // (4) republished for the other workgroups of this GPU
+        if (tid < 2)
+            put_granules(P.grec + 4 * (2 * par + tid), tag,
+                         tid == 0 ? make_double2(s_S[0], s_S[1]) : make_double2(s_S[2], s_S[3]));
+        return true;
+    }
+    bool have_g = tid >= 2, done = false;
+    for (unsigned spins = 0; spins < P.spin_limit; ++spins) {
+        bool ok = true;
+        if (!have_g) {
+            double2 v;
+            have_g = get_granules(P.grec, 64u * 2u, 64u * (uint32_t)par + 32u * (uint32_t)tid, tag, v);
+            if (have_g) s_rec[tid] = v;
+            ok = have_g;
+        }
+        fetch_halo(ok);
+        if (__syncthreads_and(ok ? 1 : 0)) {
+            done = true;
+            break;
+        }
+        if (gave_up(spins)) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if (!done) return fail();
+    if (tid < 4) s_S[tid] = ((const double *)s_rec)[tid];
+    __syncthreads();
+    return true;
+}
+
 // Workgroup totals of four partial sums for the two publishing threads (0 and 1): DPP wave trees, then the eight
 // waves in order.
 __device__ inline void persist_block_sum(double (&acc)[4], double *s_red)
@@ -2114,7 +2280,7 @@ constexpr int kPersistRegs = 5; // ring words in registers per node: 10 entries,
 constexpr int kPersistNpt = 4;  // nodes (tiles) per thread
 constexpr int kPersistNh = 2;   // halo entries per thread: a workgroup's tiles may carry 1024 halo nodes in all
 
-template <int B>
+template <int B, bool MG>
 __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistParams P)
 {
     constexpr int TG = kPersistThreads / B; // thread groups; each owns kPersistNpt of the workgroup's tiles
@@ -2132,7 +2298,8 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
     auto t_xy = [&](int s) { return smem + (size_t)(gi + TG * s) * tile_words; };
 
     constexpr int NH = kPersistNh; // halo entries per thread: the workgroup's halo nodes are dealt out over ALL threads
-    int32_t node[NPT], deg[NPT];
+    const unsigned tag0 = (MG ? P.tag_base : 0u) + 1u; // tag of epoch e: tag0 + e - 1
+    int32_t node[NPT], deg[NPT], oslot[NPT];
     int32_t hg[NH], hloc[NH]; // global id (-1: none) and LDS position (tile * tile_words-relative) of a halo entry
     uint32_t flags[NPT]; // bit 0/1 prescribed ux/uy, 2 published, 3 live tile, 4 valid node
     uint32_t w[NPT][kPersistRegs];
@@ -2143,16 +2310,17 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
 #pragma unroll
     for (int s = 0; s < NPT; ++s) {
         const int l = gi + TG * s;
-        const int32_t t = blockIdx.x * P.tiles_per_wg + l;
+        const int32_t t = (MG ? P.t0 : 0) + blockIdx.x * P.tiles_per_wg + l;
         double2 *xy = t_xy(s), *pim = xy + cap, *hr = pim + cap, *hp = hr + maxh, *xs = hp + maxh;
         node[s] = 0;
+        oslot[s] = -1;
         deg[s] = 0;
         flags[s] = 3;
         ell_off[s] = 0;
         r[s] = q[s] = make_double2(0.0, 0.0);
 #pragma unroll
         for (int k = 0; k < kPersistRegs; ++k) w[s][k] = 0xffffffffu;
-        if (!(l < P.tiles_per_wg && t < P.T)) continue;
+        if (!(l < P.tiles_per_wg && t < (MG ? P.t1 : P.T))) continue;
         const TileMeta tm = P.meta[t];
         const int64_t nd = (int64_t)t * B + lt;
         node[s] = (int32_t)nd;
@@ -2174,17 +2342,21 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
 #pragma unroll
         for (int k = 0; k < kPersistRegs; ++k)
             if (k < deg[s]) w[s][k] = P.ell16[ell_off[s] + (int64_t)k * B];
-        if ((flags[s] & 20) == 20) put_granules(P.qg + 4 * nd, 1u, make_double2(0.0, 0.0)); // q_{-1} = 0, parity 0
+        if ((flags[s] & 20) == 20) put_granules(P.qg + 4 * nd, tag0, make_double2(0.0, 0.0)); // q_{-1} = 0, parity 0
+        if (MG && (flags[s] & 16)) {
+            oslot[s] = P.own_qslot[nd];
+            if (oslot[s] >= 0) put_granules_sys(P.win_q + 4 * (int64_t)oslot[s], tag0, make_double2(0.0, 0.0));
+        }
     }
     // halo entries of the workgroup's tiles, in tile order, dealt out round-robin: thread t takes entries t, t + 512
     {
-        const int32_t t_first = blockIdx.x * P.tiles_per_wg;
+        const int32_t t_first = (MG ? P.t0 : 0) + blockIdx.x * P.tiles_per_wg, t_end = MG ? P.t1 : P.T;
 #pragma unroll
         for (int e = 0; e < NH; ++e) {
             hg[e] = -1;
             hloc[e] = 0;
             int32_t rem = tid + kPersistThreads * e;
-            for (int l = 0; l < P.tiles_per_wg && t_first + l < P.T; ++l) {
+            for (int l = 0; l < P.tiles_per_wg && t_first + l < t_end; ++l) {
                 const TileMeta tm = P.meta[t_first + l];
                 if (rem < tm.nh) {
                     double2 *xy = smem + (size_t)l * tile_words;
@@ -2194,6 +2366,10 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
                     const double2 hb = P.bP[hg[e]];
                     xy[2 * cap + rem] = make_double2(-hb.x, -hb.y);      // halo r
                     xy[2 * cap + maxh + rem] = make_double2(0.0, 0.0); // halo p
+                    if (MG) { // a node another rank owns: its q comes through the window (slot s encoded as -2 - s)
+                        const int32_t hs = P.halo_qslot[tm.hoff + rem];
+                        if (hs >= 0) hg[e] = -2 - hs;
+                    }
                     break;
                 }
                 rem -= tm.nh;
@@ -2203,12 +2379,14 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
     if (blockIdx.x == 0 && tid == 0) acc[1] = 1.0; // "p.q" > 0: alpha finite, multiplies q = 0
     persist_block_sum(acc, s_red);
     int par = 0;
-    unsigned epoch = 1;
+    unsigned epoch = tag0; // the tags of successive exchanges
     if (tid < 2) // the block sums are in every thread: two threads publish the record's two pieces
         put_granules(P.recg + 4 * (2 * ((int64_t)par * gridDim.x + blockIdx.x) + tid), epoch,
                      tid == 0 ? make_double2(acc[0], acc[1]) : make_double2(acc[2], acc[3]));
     double2 hq[NH]; // q of this thread's halo nodes
-    if (!persist_exchange<NH>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk)) return;
+    if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec)
+           : !persist_exchange<NH>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk))
+        return;
 
     const double c0 = P.c0, nu = P.nu, h = P.h;
     double target = P.tol, bb = 0.0;
@@ -2255,7 +2433,7 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
         }
 #pragma unroll
         for (int e = 0; e < NH; ++e)
-            if (hg[e] >= 0) {
+            if (hg[e] != -1) {
                 double2 *hbase = smem + hloc[e]; // = tile base + position: coordinates at [B], p image at [cap + B], ...
                 double2 hrv = hbase[2 * cap], hpv = hbase[2 * cap + maxh];
                 hrv.x += alpha * hq[e].x;
@@ -2291,6 +2469,8 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
             if ((flags[s] & 2) || !(flags[s] & 16)) fy = 0.0;
             q[s] = make_double2(fx, fy);
             if ((flags[s] & 20) == 20) put_granules(P.qg + 4 * ((int64_t)(par ^ 1) * P.N + node[s]), epoch + 1, q[s]);
+            if (MG && oslot[s] >= 0)
+                put_granules_sys(P.win_q + 4 * ((int64_t)(par ^ 1) * P.n_iface + oslot[s]), epoch + 1, q[s]);
             acc[0] += r[s].x * r[s].x + r[s].y * r[s].y;
             acc[1] += pa.x * fx + pa.y * fy;
             acc[2] += r[s].x * fx + r[s].y * fy;
@@ -2303,7 +2483,9 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
         if (tid < 2)
             put_granules(P.recg + 4 * (2 * ((int64_t)par * gridDim.x + blockIdx.x) + tid), epoch,
                          tid == 0 ? make_double2(acc[0], acc[1]) : make_double2(acc[2], acc[3]));
-        if (!persist_exchange<NH>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk)) return;
+        if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec)
+               : !persist_exchange<NH>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk))
+            return;
     }
     // x of iterate j-1 is in LDS; the verdict is the same in every workgroup
 #pragma unroll
@@ -2333,10 +2515,15 @@ size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh)
 void persist_launch(const PersistParams &P, int32_t B, int32_t grid, hipStream_t s)
 {
     const size_t lds = persist_lds_bytes(B, P.cap, P.maxh);
-    if (B == 256)
-        k_cg_persist<256><<<grid, kPersistThreads, lds, s>>>(P);
+    if (P.nranks > 1) {
+        if (B == 256)
+            k_cg_persist<256, true><<<grid, kPersistThreads, lds, s>>>(P);
+        else
+            k_cg_persist<512, true><<<grid, kPersistThreads, lds, s>>>(P);
+    } else if (B == 256)
+        k_cg_persist<256, false><<<grid, kPersistThreads, lds, s>>>(P);
     else
-        k_cg_persist<512><<<grid, kPersistThreads, lds, s>>>(P);
+        k_cg_persist<512, false><<<grid, kPersistThreads, lds, s>>>(P);
 }
 
 // bit 2 of the node mask: some tile reads this node through its halo list, so its owner must publish q

@@ -291,10 +291,21 @@ struct PersistParams {
     uint32_t *sync;           // [9] timeout word; zeroed, like the granules, before every launch
     FusedState *st;
     double *hist;
+    // multi-GPU (MG instantiation; nranks == 1 otherwise): this rank runs tiles [t0, t1) and exchanges through a
+    // window of host memory every rank has mapped (granules again, system scope): one record of sums per rank, q of the
+    // interface nodes.  Tags carry a per-solve sequence number in their upper bits, so the window is never zeroed.
+    int32_t t0, t1, rank, nranks, n_iface;
+    uint32_t tag_base;          // solve sequence << 20
+    const int32_t *own_qslot;   // N: interface slot of an owned node other ranks read, -1 otherwise
+    const int32_t *halo_qslot;  // halo_total: interface slot of a halo entry another rank owns, -1 otherwise
+    unsigned long long *win_rec; // window: 2 * nranks * 8 granules
+    unsigned long long *win_q;   // window: 2 * n_iface * 4 granules
+    uint32_t *win_tmo;           // window: timeout word
+    unsigned long long *grec;    // device: 2 * 8 granules, the grid-wide sums republished by workgroup 0
 };
 int persist_tiles_per_wg(int32_t B); // tiles one workgroup keeps on chip (0: tile size not supported)
 size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh);
-void persist_launch(const PersistParams &P, int32_t B, int32_t grid, hipStream_t s);
+void persist_launch(const PersistParams &P, int32_t B, int32_t grid, hipStream_t s); // MG kernel when nranks > 1
 void mark_published(const int32_t *halo_g, int64_t halo_total, uint8_t *maskP, hipStream_t s);
 
 // ---- fp32 leg of BASELINE config 5 (fp64 vs fp32 CG tolerance sweep): the fused iteration with the CG state, the

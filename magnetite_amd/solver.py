@@ -129,6 +129,17 @@ class Context:
         buf = (C.c_uint8 * _lib.MAG_UNIQUE_ID_BYTES).from_buffer_copy(raw)
         self._check(self._L.mag_comm_init_rccl(self._h, C.cast(buf, C.c_void_p), world, rank))
 
+    def set_window(self, shm):
+        """Multi-GPU on-chip CG: `shm` is a multiprocessing.shared_memory.SharedMemory (or None to remove the window)
+        that EVERY rank of the node has opened under the same name; see mag_comm_set_window in the header."""
+        if shm is None:
+            self._check(self._L.mag_comm_set_window(self._h, None, 0))
+            self._window = None
+            return
+        addr = C.addressof(C.c_uint8.from_buffer(shm.buf))  # the temporary export ends here: shm.close() stays possible
+        self._check(self._L.mag_comm_set_window(self._h, C.c_void_p(addr), shm.size))
+        self._window = shm  # keep the mapping alive as long as the library uses it
+
     def init_callback(self, fn, rank, world):
         """Test transport: fn(numpy_view) must sum the array over ranks in place (e.g. gloo all_reduce)."""
         import numpy as _np

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--tile", type=int, default=256)
     ap.add_argument("--precond", type=int, default=0, help="mag_options.preconditioner (checked against the oracle's PCG)")
+    ap.add_argument("--window", type=int, default=0, help="1: share a host-memory window (on-chip CG on every rank)")
     ap.add_argument("--stacked", type=int, default=0, help="bench.py's weak-scaling geometry: plate-with-hole stacked N times")
     a = ap.parse_args()
     import torch
@@ -53,9 +54,33 @@ def main():
             t = torch.from_numpy(arr)
             dist.all_reduce(t)
 
-        with Context(device=0, tile_nodes=a.tile, cg_variant=a.variant, preconditioner=a.precond) as c:
+        shm = None
+        if a.window:
+            from multiprocessing import shared_memory
+            names = [None]
+            if rank == 0:
+                shm = shared_memory.SharedMemory(create=True, size=8 << 20)
+                names[0] = shm.name
+            dist.broadcast_object_list(names, src=0)
+            if rank != 0:
+                shm = shared_memory.SharedMemory(name=names[0])
+        with Context(device=0, tile_nodes=a.tile, cg_variant=2 if a.window else a.variant, preconditioner=a.precond) as c:
             c.init_callback(allreduce, rank, world)
+            if shm is not None:
+                c.set_window(shm)
             out = c.solve(prob)
+            kernel = c.stats()["cg_kernel"]
+            if a.window:
+                out2 = c.solve(prob)                       # a second solve: new tags, same window
+                assert np.array_equal(out2["u"], out["u"]) and c.stats()["cg_kernel"] == kernel
+                c.set_window(None)
+        if a.window:
+            print(f"rank {rank}: cg_kernel {kernel}", flush=True)
+            assert kernel == 2, kernel
+            dist.barrier()
+            shm.close()
+            if rank == 0:
+                shm.unlink()
     ref = oracle.run(prob.xy_flat, prob.conn_flat, prob.u_known, prob.u_in, prob.f_in, prob.youngs_modulus,
                      prob.poisson_ratio, prob.part_thickness, path="sparse", precond=a.precond)
     err = np.linalg.norm(out["u"] - ref["u"]) / np.linalg.norm(ref["u"])

@@ -31,6 +31,16 @@ def test_four_ranks_on_the_weak_scaling_geometry(built):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+@pytest.mark.parametrize("nproc", [2, 3])
+def test_on_chip_cg_across_ranks_through_a_host_window(built, nproc):
+    """Every rank runs its share of the mesh as one persistent launch; per iteration the ranks exchange one record of
+    sums and the q of the interface nodes through a window of shared host memory (tagged granules, system scope).  On
+    this one-GPU box the ranks' kernels run side by side on the same GPU; on a node each rank has its own."""
+    r = launch(nproc, "callback", 29577 + nproc, 1, ("--window", "1", "--tile", "512", "--mesh", "120"),
+               {"MAG_TUNE_PERSIST_MIN_K": "1"})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_two_ranks_several_tiles_per_workgroup(built):
     """MAG_TUNE_GRID=4: every workgroup of the COMM kernel walks several tiles, ghost loop strided over few workgroups"""
     r = launch(2, "callback", 29576, 1, ("--precond", "2"), {"MAG_TUNE_GRID": "4"})
