@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="world size 1 only: still create the nccl process group and the RCCL communicator and run "
                          "the distributed CG protocol (iteration kernel + one in-place all-reduce every iteration)")
+    ap.add_argument("--no-window", action="store_true",
+                    help="N > 1: no shared host-memory window, i.e. the streaming kernels + one RCCL all-reduce per "
+                         "CG iteration instead of the multi-GPU on-chip CG")
     ap.add_argument("--share-gpu", action="store_true",
                     help="REHEARSAL of the N > 1 code path on a one-GPU box: every rank drives GPU 0 and the collectives "
                          "go through gloo (host callback) instead of RCCL; the printed line is marked, it is no result")
@@ -145,6 +148,35 @@ def main():
         ctx.init_callback(host_allreduce, rank, world)
     elif use_dist:
         ctx.init_rccl_from_torch(dist, rank, world)
+    shm = None
+    if world > 1 and args.cg_variant == 2 and not args.no_window:
+        # multi-GPU on-chip CG: a window of shared host memory for the per-iteration exchange (mag_comm_set_window)
+        from multiprocessing import shared_memory
+        names = [None]
+        if rank == 0:
+            shm = shared_memory.SharedMemory(create=True, size=32 << 20)
+            names[0] = shm.name
+        dist.broadcast_object_list(names, src=0)
+        ok = 1
+        try:
+            if rank != 0:
+                shm = shared_memory.SharedMemory(name=names[0])
+                from multiprocessing import resource_tracker
+                resource_tracker.unregister(shm._name, "shared_memory")  # rank 0 owns the segment (Python < 3.13)
+            ctx.set_window(shm)
+        except Exception as exc:  # e.g. the runtime refuses to map the pages: every rank must then do without
+            print(f"rank {rank}: no host-memory window ({exc}); streaming kernels + RCCL", file=sys.stderr, flush=True)
+            ok = 0
+        t_ok = torch.tensor([ok], dtype=torch.int32, device="cpu" if args.share_gpu else "cuda")
+        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+        if int(t_ok.item()) == 0:
+            if ok:
+                ctx.set_window(None)
+            if shm is not None:
+                shm.close()
+                if rank == 0:
+                    shm.unlink()
+            shm = None
     ctx.upload_problem(prob)  # inputs resident in HBM before the timed region
 
     def barrier():
@@ -210,7 +242,9 @@ def main():
             "config": {"workload": f"{args.workload}: {desc}, {E} triangles, {N} nodes, left edge fixed, "
                                    f"right edge ux=delta; full solver::run per step; CG stop={args.stop} tol={args.tol:g}",
                        "elements": E, "nodes": N, "tile_nodes": args.tile, "cg_variant": args.cg_variant, "cg_kernel": kind, "cg_stop": args.stop, "cg_tol": args.tol,
-                       "parallelism": f"strips{world}" if world > 1 else "single"},
+                       "parallelism": f"strips{world}" if world > 1 else "single",
+                       "exchange": (("host-memory window (granules)" if kind == 2 else "RCCL all-reduce per iteration")
+                                    if world > 1 else None)},
             "roofline": {"bound": "hbm",
                          "kernel": {2: "k_cg_persist<%d> (the whole CG solve in one launch: state resident in registers "
                                        "and LDS, grid-wide exchange by tagged granules every iteration)" % args.tile,
@@ -249,7 +283,14 @@ def main():
             out["rehearsal"] = "ranks share GPU 0, collectives through gloo: exercises the N > 1 code path, not a result"
         print(json.dumps(out), flush=True)
 
+    if shm is not None:
+        ctx.set_window(None)
     ctx.close()
+    if shm is not None:
+        barrier()
+        shm.close()
+        if rank == 0:
+            shm.unlink()
     if use_dist:
         dist.destroy_process_group()
 

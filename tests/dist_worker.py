@@ -64,6 +64,8 @@ def main():
             dist.broadcast_object_list(names, src=0)
             if rank != 0:
                 shm = shared_memory.SharedMemory(name=names[0])
+                from multiprocessing import resource_tracker
+                resource_tracker.unregister(shm._name, "shared_memory")  # rank 0 owns the segment (Python < 3.13)
         with Context(device=0, tile_nodes=a.tile, cg_variant=2 if a.window else a.variant, preconditioner=a.precond) as c:
             c.init_callback(allreduce, rank, world)
             if shm is not None:

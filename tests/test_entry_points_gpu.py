@@ -52,6 +52,8 @@ def test_bench_multi_rank_code_path_on_one_gpu(built):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None and "rehearsal" in d
     assert d["config"]["parallelism"] == "strips2" and d["config"]["elements"] == 2 * 100352
     assert d["cg_converged"] == 1 and d["value"] > 0
+    # two ranks x ~50 workgroups fit the one GPU side by side: the multi-GPU on-chip CG runs, exchanging through the window
+    assert d["config"]["cg_kernel"] == 2 and "window" in d["config"]["exchange"]
 
 
 def test_smoke_entry_point(built):
