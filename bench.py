@@ -101,9 +101,10 @@ def main():
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="world size 1 only: still create the nccl process group and the RCCL communicator and run "
                          "the distributed CG protocol (iteration kernel + one in-place all-reduce every iteration)")
-    ap.add_argument("--no-window", action="store_true",
-                    help="N > 1: no shared host-memory window, i.e. the streaming kernels + one RCCL all-reduce per "
-                         "CG iteration instead of the multi-GPU on-chip CG")
+    ap.add_argument("--window", action="store_true",
+                    help="N > 1, EXPERIMENTAL: share a host-memory window so that every rank runs the on-chip CG and the "
+                         "per-iteration exchange goes through it (measured slower than one RCCL all-reduce per "
+                         "iteration once a rank has more than a few hundred interface nodes; default off)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="REHEARSAL of the N > 1 code path on a one-GPU box: every rank drives GPU 0 and the collectives "
                          "go through gloo (host callback) instead of RCCL; the printed line is marked, it is no result")
@@ -149,7 +150,7 @@ def main():
     elif use_dist:
         ctx.init_rccl_from_torch(dist, rank, world)
     shm = None
-    if world > 1 and args.cg_variant == 2 and not args.no_window:
+    if world > 1 and args.cg_variant == 2 and args.window:
         # multi-GPU on-chip CG: a window of shared host memory for the per-iteration exchange (mag_comm_set_window)
         from multiprocessing import shared_memory
         names = [None]

@@ -222,7 +222,9 @@ int mag_comm_init_rccl(mag_ctx *ctx, const void *unique_id, int32_t nranks, int3
 /* test transport: sum-all-reduce of a host buffer supplied by the caller (gloo in tests/) */
 typedef int (*mag_allreduce_fn)(void *user, double *host_buf, int64_t count);
 int mag_comm_init_callback(mag_ctx *ctx, int32_t nranks, int32_t rank, mag_allreduce_fn fn, void *user);
-/* Multi-GPU on-chip CG: a window of HOST memory that every rank of the node has mapped at `host_ptr` (the same
+/* EXPERIMENTAL multi-GPU on-chip CG (correct, but slower than the default once a rank has more than a few hundred
+ * interface nodes: every granule is its own PCIe transaction -- see DESIGN.md): a window of HOST memory that every
+ * rank of the node has mapped at `host_ptr` (the same
  * physical pages: POSIX shared memory, bytes >= 64 + 128 * nranks + 64 * interface nodes; a few MB is plenty).  With a
  * window and cg_variant 2 each rank runs its share of the mesh as ONE persistent launch and the per-iteration
  * exchange (one record of sums per rank, q of the interface nodes) goes through the window as tagged granules instead

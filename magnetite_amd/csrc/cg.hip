@@ -2099,18 +2099,15 @@ __device__ inline void put_granules_sys(unsigned long long *g, unsigned tag, dou
                            __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__device__ inline bool get_granules_sys(const unsigned long long *g, unsigned tag, double2 &v)
+// `base` wave-uniform, as for get_granules; sc0 | sc1 = system scope: the loads go to the host memory itself.
+__device__ inline bool get_granules_sys(const unsigned long long *base, uint32_t bytes, uint32_t off, unsigned tag,
+                                        double2 &v)
 {
-    unsigned long long x[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) x[k] = __hip_atomic_load((gu64 *)g + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    unsigned w[4];
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        ok &= (unsigned)(x[k] >> 32) == tag;
-        w[k] = (unsigned)x[k];
-    }
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, (short)0, (int)bytes, 0x00020000);
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 17);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off + 16, 0, 17);
+    const bool ok = a.y == tag && a.w == tag && b.y == tag && b.w == tag;
+    unsigned w[4] = {a.x, a.z, b.x, b.z};
     __builtin_memcpy(&v, w, 16);
     return ok;
 }
@@ -2152,14 +2149,29 @@ __device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsi
         }
         return false;
     };
-    auto fetch_halo = [&](bool &ok) {
+    // Window reads cross PCIe: they are issued only once the grid-wide sums are known -- every rank wrote its q before
+    // its record (posted writes of one device stay in order), so by then they are there and ONE read per value does
+    // (each granule still validates itself; a miss is simply read again).
+    auto fetch_halo = [&](bool &ok, bool window) {
 #pragma unroll
         for (int e = 0; e < NH; ++e)
             if (!have_h[e]) {
-                have_h[e] = hg[e] >= 0 ? get_granules(qbase, 32u * (uint32_t)P.N, 32u * (uint32_t)hg[e], tag, hq[e])
-                                       : get_granules_sys(wq + 4 * (int64_t)(-2 - hg[e]), tag, hq[e]);
-                ok &= have_h[e];
+                if (hg[e] >= 0)
+                    have_h[e] = get_granules(qbase, 32u * (uint32_t)P.N, 32u * (uint32_t)hg[e], tag, hq[e]);
+                else if (window)
+                    have_h[e] = get_granules_sys(wq, 32u * (uint32_t)P.n_iface, 32u * (uint32_t)(-2 - hg[e]), tag, hq[e]);
+                ok &= have_h[e] || (hg[e] < 0 && !window);
             }
+    };
+    auto fetch_window_halo = [&]() { // after the sums: bounded retries
+        for (unsigned spins = 0; spins < P.spin_limit; ++spins) {
+            bool ok = true;
+            fetch_halo(ok, true);
+            if (__syncthreads_and(ok ? 1 : 0)) return true;
+            if (gave_up(spins)) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        return false;
     };
     __builtin_amdgcn_s_sleep(20);
     __builtin_amdgcn_s_sleep(20);
@@ -2175,7 +2187,7 @@ __device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsi
                 if (have_rec) s_rec[tid] = v;
                 ok = have_rec;
             }
-            fetch_halo(ok);
+            fetch_halo(ok, false);
             if (__syncthreads_and(ok ? 1 : 0)) {
                 done = true;
                 break;
@@ -2207,7 +2219,7 @@ __device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsi
         for (; spins < P.spin_limit; ++spins) {
             if (!have_w) {
                 double2 v;
-                have_w = get_granules_sys(P.win_rec + 4 * (2 * (int64_t)par * R + tid), tag, v);
+                have_w = get_granules_sys(P.win_rec + 8 * (int64_t)par * R, 64u * (uint32_t)R, 32u * (uint32_t)tid, tag, v);
                 if (have_w) s_rec[tid] = v;
             }
             if (__syncthreads_and(have_w ? 1 : 0)) {
@@ -2229,7 +2241,7 @@ __device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsi
         if (tid < 2)
             put_granules(P.grec + 4 * (2 * par + tid), tag,
                          tid == 0 ? make_double2(s_S[0], s_S[1]) : make_double2(s_S[2], s_S[3]));
-        return true;
+        return fetch_window_halo() ? true : fail();
     }
     bool have_g = tid >= 2, done = false;
     for (unsigned spins = 0; spins < P.spin_limit; ++spins) {
@@ -2240,7 +2252,7 @@ __device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsi
             if (have_g) s_rec[tid] = v;
             ok = have_g;
         }
-        fetch_halo(ok);
+        fetch_halo(ok, false);
         if (__syncthreads_and(ok ? 1 : 0)) {
             done = true;
             break;
@@ -2251,7 +2263,7 @@ __device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsi
     if (!done) return fail();
     if (tid < 4) s_S[tid] = ((const double *)s_rec)[tid];
     __syncthreads();
-    return true;
+    return fetch_window_halo() ? true : fail();
 }
 
 // Workgroup totals of four partial sums for the two publishing threads (0 and 1): DPP wave trees, then the eight

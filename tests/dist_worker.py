@@ -73,6 +73,8 @@ def main():
             out = c.solve(prob)
             kernel = c.stats()["cg_kernel"]
             if a.window:
+                print(f"rank {rank}: on-chip across ranks: {out['iterations']} iterations, "
+                      f"{c.stats()['ms_cg'] * 1e3 / max(1, out['iterations']):.2f} us per iteration", flush=True)
                 out2 = c.solve(prob)                       # a second solve: new tags, same window
                 assert np.array_equal(out2["u"], out["u"]) and c.stats()["cg_kernel"] == kernel
                 c.set_window(None)

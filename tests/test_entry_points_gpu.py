@@ -36,13 +36,15 @@ def test_bench_prints_one_contract_line(built):
     assert d["value"] > 10.0 * cb["value"]          # north_star: >= 10x the CPU solver at 1 GPU
 
 
-def test_bench_multi_rank_code_path_on_one_gpu(built):
+@pytest.mark.parametrize("window", [False, True], ids=["rccl-path", "host-window"])
+def test_bench_multi_rank_code_path_on_one_gpu(built, window):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed with both
     ranks on the one GPU and gloo in place of RCCL (--share-gpu): stacked weak-scaling mesh, barriers, max-over-ranks
     timing, rank 0 prints the single line."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-           "127.0.0.1", "--master-port", "29581", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu",
-           "--workload", "plate100k", "--steps", "1", "--warmup", "1", "--op-reps", "20"]
+           "127.0.0.1", "--master-port", str(29581 + (1 if window else 0)), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--share-gpu", "--workload", "plate100k", "--steps", "1", "--warmup", "1", "--op-reps", "20"] + \
+          (["--window"] if window else [])
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
@@ -52,8 +54,10 @@ def test_bench_multi_rank_code_path_on_one_gpu(built):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None and "rehearsal" in d
     assert d["config"]["parallelism"] == "strips2" and d["config"]["elements"] == 2 * 100352
     assert d["cg_converged"] == 1 and d["value"] > 0
-    # two ranks x ~50 workgroups fit the one GPU side by side: the multi-GPU on-chip CG runs, exchanging through the window
-    assert d["config"]["cg_kernel"] == 2 and "window" in d["config"]["exchange"]
+    if window:  # two ranks x ~50 workgroups fit the one GPU side by side: the multi-GPU on-chip CG runs
+        assert d["config"]["cg_kernel"] == 2 and "window" in d["config"]["exchange"]
+    else:       # default: streaming kernels, one all-reduce per iteration
+        assert d["config"]["cg_kernel"] == 1
 
 
 def test_smoke_entry_point(built):
