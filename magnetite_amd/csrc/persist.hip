@@ -1,0 +1,621 @@
+// On-chip conjugate gradients: the whole solve in one launch (see the comment below).  Its own translation unit because
+// it is compiled with a different instruction scheduler than the streaming kernels of cg.hip (Makefile).
+#include <cstdlib>
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+
+#include "cg_device.h"
+#include "kernels.h"
+
+namespace magk {
+
+// ============================================ on-chip (persistent) CG ===
+// When the whole mesh fits the chip -- every workgroup keeps 2 * (1024 / B) tiles: r, q, p, x of their nodes in
+// registers, coordinates and the p image in LDS, the ring words in registers -- the CG state never moves through
+// HBM again: ONE launch runs the whole solve.  Per iteration a workgroup only publishes q of the nodes other tiles
+// read and its four dot partials, as tagged granules (below); every workgroup then sweeps every workgroup's record
+// and the q of its own halo nodes until all tags carry the iteration's epoch -- that sweep IS the grid barrier -- and
+// sums the records in one fixed order: the same bits in every workgroup, so all of them take the same stop decision
+// in the same iteration.  Spins are bounded (a workgroup that gives up sets the timeout word and leaves; the host
+// then falls back to the streaming kernels).  Same recurrences and state machine as
+// k_cg_fused (alpha, beta from the four exact sums of the previous iterate).
+typedef __attribute__((address_space(1))) unsigned int gu32;
+constexpr int kPersistThreads = 512; // 8 waves per CU = 2 per SIMD: 256 VGPRs per lane, no spills with 4 nodes per thread
+
+// Inter-workgroup exchange by self-validating granules (CDNA4 guide, Guideline 16 R2: "the data IS the flag"): every
+// handed-off 32-bit half travels in its own naturally aligned 8-byte word {tag = epoch, value}, written by ONE relaxed
+// agent-scope atomic store and read by relaxed agent-scope atomic loads until the tag matches.  No arrival counters,
+// no store drains, no fences: a reader can never take a stale or torn value for the current one.  Two buffers by
+// parity: nobody can be two epochs ahead of a workgroup that has not finished reading (it would need that workgroup's
+// next record first).
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+__device__ inline void put_granules(unsigned long long *g, unsigned epoch, double2 v)
+{
+    unsigned w[4];
+    __builtin_memcpy(w, &v, 16);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        __hip_atomic_store((gu64 *)g + k, ((unsigned long long)epoch << 32) | w[k], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Four granules (32 bytes) by two 16-byte sc1 loads: each 8-byte granule was written by one atomic store and validates
+// itself, so it does not matter that the pair is not read atomically.  `base` must be wave-uniform (it becomes the
+// buffer resource), the granule group is addressed by the per-lane byte offset.
+__device__ inline bool get_granules(const unsigned long long *base, uint32_t bytes, uint32_t off, unsigned epoch,
+                                    double2 &v)
+{
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, (short)0, (int)bytes, 0x00020000);
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 16);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off + 16, 0, 16);
+    const bool ok = a.y == epoch && a.w == epoch && b.y == epoch && b.w == epoch;
+    unsigned w[4] = {a.x, a.z, b.x, b.z};
+    __builtin_memcpy(&v, w, 16);
+    return ok;
+}
+
+// Sum over the 64 lanes of a wave by DPP (ALU-rate lane moves; __shfl_down goes through the LDS crossbar, ~10x the
+// latency per step, and the on-chip kernel has only two waves per SIMD to hide it).  Inclusive scan inside each row
+// of 16 lanes (row_shr 1, 2, 4, 8), then row 0 -> row 1 and row 2 -> row 3 (row_bcast:15), then lane 31 -> rows 2, 3
+// (row_bcast:31): the total is in lane 63 and comes back in every lane.  A fixed order, like every sum here.
+__device__ inline double wave_sum_dpp(double v)
+{
+#define MAG_DPP_STEP(CTRL, ROWMASK)                                                                                  \
+    {                                                                                                                  \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, false);                   \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, false);                   \
+        v += __hiloint2double(hi, lo);                                                                                 \
+    }
+    MAG_DPP_STEP(0x111, 0xf) // row_shr:1
+    MAG_DPP_STEP(0x112, 0xf) // row_shr:2
+    MAG_DPP_STEP(0x114, 0xf) // row_shr:4
+    MAG_DPP_STEP(0x118, 0xf) // row_shr:8
+    MAG_DPP_STEP(0x142, 0xa) // row_bcast:15 into rows 1 and 3
+    MAG_DPP_STEP(0x143, 0xc) // row_bcast:31 into rows 2 and 3
+#undef MAG_DPP_STEP
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
+                            __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+// Wait for epoch `epoch`: every workgroup's partial record (two 16-byte pieces each, one per thread) and the q of this
+// thread's halo nodes, swept together until every tag matches; then the records are summed in one fixed two-level
+// order (chunks of eight workgroups, then the chunks) so that all workgroups hold the same bits.  grid <= 256.
+// Returns false when the spin budget runs out (some workgroup is not running): the timeout word is set for the host.
+template <int NH>
+__device__ inline bool persist_exchange(const PersistParams &P, int par, unsigned epoch, const int32_t (&hg)[NH],
+                                        double2 (&hq)[NH], double *s_S, double2 *s_rec, double *s_chunk)
+{
+    const int tid = threadIdx.x;
+    const int grid = gridDim.x;
+    gu32 *tmo = (gu32 *)P.sync + 9;
+    // One sweep fetches what is still missing of both: a 16-byte piece of the records per thread and the q of this
+    // thread's halo nodes.
+    const unsigned long long *recb = P.recg + 8 * (int64_t)par * grid; // this parity's records: 64 bytes per workgroup
+    const unsigned long long *qbase = P.qg + 4 * (int64_t)par * P.N;   // ... and q granules: 32 bytes per node
+    bool have_rec = tid >= 2 * grid, have_h[NH];
+#pragma unroll
+    for (int s = 0; s < NH; ++s) {
+        have_h[s] = hg[s] < 0;
+        hq[s] = make_double2(0.0, 0.0);
+    }
+    bool done = false;
+    __builtin_amdgcn_s_sleep(20); // ~1 us in all: the other workgroups' records are still on their way, and a sweep
+    __builtin_amdgcn_s_sleep(20); // that comes too early costs a full round trip (measured optimum: 0 -> 15.1 us per
+                                  // iteration, 20+20 -> 13.5, 30+30 -> 14.0)
+    for (unsigned spins = 0; spins < P.spin_limit; ++spins) {
+        bool ok = true;
+        if (!have_rec) {
+            double2 v;
+            have_rec = get_granules(recb, 64u * (uint32_t)grid, 32u * (uint32_t)tid, epoch, v);
+            if (have_rec) s_rec[tid] = v;
+            ok = have_rec;
+        }
+#pragma unroll
+        for (int s = 0; s < NH; ++s)
+            if (!have_h[s]) {
+                have_h[s] = get_granules(qbase, 32u * (uint32_t)P.N, 32u * (uint32_t)hg[s], epoch, hq[s]);
+                ok &= have_h[s];
+            }
+        if (__syncthreads_and(ok ? 1 : 0)) {
+            done = true;
+            break;
+        }
+        if ((spins & 255u) == 255u) { // somebody else gave up: do not wait for a grid that will never be complete
+            const int dead =
+                tid == 0 && __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ? 1 : 0;
+            if (__syncthreads_or(dead)) break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (!done) {
+        if (tid == 0) __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+    }
+    // every workgroup sums the same values in the same order (four records per lane, then the lanes): same bits
+    // everywhere
+    __syncthreads(); // s_rec complete
+    if (tid < 64) {
+        double S[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int m = tid; m < grid; m += 64) {
+            const double2 a = s_rec[2 * m], b = s_rec[2 * m + 1];
+            S[0] += a.x;
+            S[1] += a.y;
+            S[2] += b.x;
+            S[3] += b.y;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) S[c] = wave_sum_dpp(S[c]);
+        if (tid < 4) s_S[tid] = tid == 0 ? S[0] : (tid == 1 ? S[1] : (tid == 2 ? S[2] : S[3]));
+    }
+    __syncthreads();
+    return true;
+}
+
+// ---- multi-GPU: the same granules through a window of HOST memory every rank has mapped (system scope) ----
+__device__ inline void put_granules_sys(unsigned long long *g, unsigned tag, double2 v)
+{
+    unsigned w[4];
+    __builtin_memcpy(w, &v, 16);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        __hip_atomic_store((gu64 *)g + k, ((unsigned long long)tag << 32) | w[k], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// `base` wave-uniform, as for get_granules; sc0 | sc1 = system scope: the loads go to the host memory itself.
+__device__ inline bool get_granules_sys(const unsigned long long *base, uint32_t bytes, uint32_t off, unsigned tag,
+                                        double2 &v)
+{
+    auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)base, (short)0, (int)bytes, 0x00020000);
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 17);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off + 16, 0, 17);
+    const bool ok = a.y == tag && a.w == tag && b.y == tag && b.w == tag;
+    unsigned w[4] = {a.x, a.z, b.x, b.z};
+    __builtin_memcpy(&v, w, 16);
+    return ok;
+}
+
+// Exchange of the multi-GPU kernel.  Halo q: from this GPU's granules, or from the window when another rank owns the
+// node (hg < 0 encodes the interface slot as -2 - slot).  Sums: workgroup 0 gathers this rank's records, publishes
+// their sum in the window, gathers every rank's record there, sums them in rank order and republishes the result on
+// the device; all other workgroups wait for that republished record.  Every workgroup on every rank ends with the
+// same bits.
+template <int NH>
+__device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsigned tag, const int32_t (&hg)[NH],
+                                           double2 (&hq)[NH], double *s_S, double2 *s_rec)
+{
+    const int tid = threadIdx.x;
+    const int grid = gridDim.x, R = P.nranks;
+    gu32 *tmo = (gu32 *)P.sync + 9;
+    gu32 *wtmo = (gu32 *)P.win_tmo;
+    const unsigned long long *recb = P.recg + 8 * (int64_t)par * grid;
+    const unsigned long long *qbase = P.qg + 4 * (int64_t)par * P.N;
+    const unsigned long long *wq = P.win_q + 4 * (int64_t)par * P.n_iface;
+    const bool lead = blockIdx.x == 0;
+    bool have_h[NH];
+#pragma unroll
+    for (int e = 0; e < NH; ++e) {
+        have_h[e] = hg[e] == -1;
+        hq[e] = make_double2(0.0, 0.0);
+    }
+    auto gave_up = [&](unsigned spins) { // uniform: every 256th spin one lane looks at the two timeout words
+        if ((spins & 255u) != 255u) return false;
+        const int dead = tid == 0 && (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                                      __hip_atomic_load(wtmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
+                             ? 1 : 0;
+        return __syncthreads_or(dead) != 0;
+    };
+    auto fail = [&]() {
+        if (tid == 0) {
+            __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(wtmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return false;
+    };
+    // Window reads cross PCIe: they are issued only once the grid-wide sums are known -- every rank wrote its q before
+    // its record (posted writes of one device stay in order), so by then they are there and ONE read per value does
+    // (each granule still validates itself; a miss is simply read again).
+    auto fetch_halo = [&](bool &ok, bool window) {
+#pragma unroll
+        for (int e = 0; e < NH; ++e)
+            if (!have_h[e]) {
+                if (hg[e] >= 0)
+                    have_h[e] = get_granules(qbase, 32u * (uint32_t)P.N, 32u * (uint32_t)hg[e], tag, hq[e]);
+                else if (window)
+                    have_h[e] = get_granules_sys(wq, 32u * (uint32_t)P.n_iface, 32u * (uint32_t)(-2 - hg[e]), tag, hq[e]);
+                ok &= have_h[e] || (hg[e] < 0 && !window);
+            }
+    };
+    auto fetch_window_halo = [&]() { // after the sums: bounded retries
+        for (unsigned spins = 0; spins < P.spin_limit; ++spins) {
+            bool ok = true;
+            fetch_halo(ok, true);
+            if (__syncthreads_and(ok ? 1 : 0)) return true;
+            if (gave_up(spins)) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        return false;
+    };
+    __builtin_amdgcn_s_sleep(20);
+    __builtin_amdgcn_s_sleep(20);
+    if (lead) {
+        // (1) this rank's records (and this workgroup's own halo values)
+        bool have_rec = tid >= 2 * grid, done = false;
+        unsigned spins = 0;
+        for (; spins < P.spin_limit; ++spins) {
+            bool ok = true;
+            if (!have_rec) {
+                double2 v;
+                have_rec = get_granules(recb, 64u * (uint32_t)grid, 32u * (uint32_t)tid, tag, v);
+                if (have_rec) s_rec[tid] = v;
+                ok = have_rec;
+            }
+            fetch_halo(ok, false);
+            if (__syncthreads_and(ok ? 1 : 0)) {
+                done = true;
+                break;
+            }
+            if (gave_up(spins)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!done) return fail();
+        if (tid < 64) {
+            double S[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int m = tid; m < grid; m += 64) {
+                const double2 a = s_rec[2 * m], b = s_rec[2 * m + 1];
+                S[0] += a.x;
+                S[1] += a.y;
+                S[2] += b.x;
+                S[3] += b.y;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) S[c] = wave_sum_dpp(S[c]);
+            // (2) this rank's sums into the window
+            if (tid < 2)
+                put_granules_sys(P.win_rec + 4 * (2 * ((int64_t)par * R + P.rank) + tid), tag,
+                                 tid == 0 ? make_double2(S[0], S[1]) : make_double2(S[2], S[3]));
+        }
+        __syncthreads();
+        // (3) every rank's sums from the window
+        bool have_w = tid >= 2 * R;
+        done = false;
+        for (; spins < P.spin_limit; ++spins) {
+            if (!have_w) {
+                double2 v;
+                have_w = get_granules_sys(P.win_rec + 8 * (int64_t)par * R, 64u * (uint32_t)R, 32u * (uint32_t)tid, tag, v);
+                if (have_w) s_rec[tid] = v;
+            }
+            if (__syncthreads_and(have_w ? 1 : 0)) {
+                done = true;
+                break;
+            }
+            if (gave_up(spins)) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (!done) return fail();
+        if (tid < 4) { // rank order: the same bits on every rank
+            const double *rec = (const double *)s_rec;
+            double t = 0.0;
+            for (int r = 0; r < R; ++r) t += rec[4 * r + tid];
+            s_S[tid] = t;
+        }
+        __syncthreads();
+        // (4) republished for the other workgroups of this GPU
+        if (tid < 2)
+            put_granules(P.grec + 4 * (2 * par + tid), tag,
+                         tid == 0 ? make_double2(s_S[0], s_S[1]) : make_double2(s_S[2], s_S[3]));
+        return fetch_window_halo() ? true : fail();
+    }
+    bool have_g = tid >= 2, done = false;
+    for (unsigned spins = 0; spins < P.spin_limit; ++spins) {
+        bool ok = true;
+        if (!have_g) {
+            double2 v;
+            have_g = get_granules(P.grec, 64u * 2u, 64u * (uint32_t)par + 32u * (uint32_t)tid, tag, v);
+            if (have_g) s_rec[tid] = v;
+            ok = have_g;
+        }
+        fetch_halo(ok, false);
+        if (__syncthreads_and(ok ? 1 : 0)) {
+            done = true;
+            break;
+        }
+        if (gave_up(spins)) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if (!done) return fail();
+    if (tid < 4) s_S[tid] = ((const double *)s_rec)[tid];
+    __syncthreads();
+    return fetch_window_halo() ? true : fail();
+}
+
+// Workgroup totals of four partial sums for the two publishing threads (0 and 1): DPP wave trees, then the eight
+// waves in order.
+__device__ inline void persist_block_sum(double (&acc)[4], double *s_red)
+{
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = wave_sum_dpp(acc[c]);
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s_red[c * (kPersistThreads / 64) + (threadIdx.x >> 6)] = acc[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < kPersistThreads / 64; ++i) t += s_red[c * (kPersistThreads / 64) + i];
+            acc[c] = t;
+        }
+    }
+}
+
+constexpr int kPersistRegs = 5; // ring words in registers per node: 10 entries, a closed fan of valence <= 9
+constexpr int kPersistNpt = 4;  // nodes (tiles) per thread
+constexpr int kPersistNh = 2;   // halo entries per thread: a workgroup's tiles may carry 1024 halo nodes in all
+
+template <int B, bool MG>
+__global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistParams P)
+{
+    constexpr int TG = kPersistThreads / B; // thread groups; each owns kPersistNpt of the workgroup's tiles
+    constexpr int NPT = kPersistNpt;
+    extern __shared__ __attribute__((aligned(16))) double2 smem[];
+    const int tid = threadIdx.x, gi = tid / B, lt = tid % B;
+    const int cap = P.cap, maxh = P.maxh;
+    // LDS per local tile l: coordinates[cap], p image[cap] (owned part = the CG vector p itself), halo r[maxh],
+    // halo p[maxh], x[B].  Registers per node: r, q, the ring words.
+    const int tile_words = 2 * cap + 2 * maxh + B;
+    double2 *s_rec = smem + (size_t)NPT * TG * tile_words; // 2 * grid pieces of the partial records
+    double *s_red = (double *)(s_rec + 2 * 256);
+    double *s_S = s_red + 4 * (kPersistThreads / 64);
+    double *s_chunk = s_S + 4;
+    auto t_xy = [&](int s) { return smem + (size_t)(gi + TG * s) * tile_words; };
+
+    constexpr int NH = kPersistNh; // halo entries per thread: the workgroup's halo nodes are dealt out over ALL threads
+    const unsigned tag0 = (MG ? P.tag_base : 0u) + 1u; // tag of epoch e: tag0 + e - 1
+    int32_t node[NPT], deg[NPT], oslot[NPT];
+    int32_t hg[NH], hloc[NH]; // global id (-1: none) and LDS position (tile * tile_words-relative) of a halo entry
+    uint32_t flags[NPT]; // bit 0/1 prescribed ux/uy, 2 published, 3 live tile, 4 valid node
+    uint32_t w[NPT][kPersistRegs];
+    int64_t ell_off[NPT];
+    double2 r[NPT], q[NPT];
+
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < NPT; ++s) {
+        const int l = gi + TG * s;
+        const int32_t t = (MG ? P.t0 : 0) + blockIdx.x * P.tiles_per_wg + l;
+        double2 *xy = t_xy(s), *pim = xy + cap, *hr = pim + cap, *hp = hr + maxh, *xs = hp + maxh;
+        node[s] = 0;
+        oslot[s] = -1;
+        deg[s] = 0;
+        flags[s] = 3;
+        ell_off[s] = 0;
+        r[s] = q[s] = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int k = 0; k < kPersistRegs; ++k) w[s][k] = 0xffffffffu;
+        if (!(l < P.tiles_per_wg && t < (MG ? P.t1 : P.T))) continue;
+        const TileMeta tm = P.meta[t];
+        const int64_t nd = (int64_t)t * B + lt;
+        node[s] = (int32_t)nd;
+        flags[s] = 8;
+        if (nd < P.N) {
+            const double2 b = P.bP[nd];
+            r[s] = make_double2(-b.x, -b.y);
+            xy[lt] = P.xyP[nd];
+            flags[s] |= 16u | (uint32_t)(P.maskP[nd] & 7);
+            acc[0] += b.x * b.x + b.y * b.y;
+        } else {
+            xy[lt] = make_double2(0.0, 0.0);
+            flags[s] |= 3;
+        }
+        pim[lt] = make_double2(0.0, 0.0);
+        xs[lt] = make_double2(0.0, 0.0);
+        deg[s] = tm.deg;
+        ell_off[s] = tm.ell_off + lt;
+#pragma unroll
+        for (int k = 0; k < kPersistRegs; ++k)
+            if (k < deg[s]) w[s][k] = P.ell16[ell_off[s] + (int64_t)k * B];
+        if ((flags[s] & 20) == 20) put_granules(P.qg + 4 * nd, tag0, make_double2(0.0, 0.0)); // q_{-1} = 0, parity 0
+        if (MG && (flags[s] & 16)) {
+            oslot[s] = P.own_qslot[nd];
+            if (oslot[s] >= 0) put_granules_sys(P.win_q + 4 * (int64_t)oslot[s], tag0, make_double2(0.0, 0.0));
+        }
+    }
+    // halo entries of the workgroup's tiles, in tile order, dealt out round-robin: thread t takes entries t, t + 512
+    {
+        const int32_t t_first = (MG ? P.t0 : 0) + blockIdx.x * P.tiles_per_wg, t_end = MG ? P.t1 : P.T;
+#pragma unroll
+        for (int e = 0; e < NH; ++e) {
+            hg[e] = -1;
+            hloc[e] = 0;
+            int32_t rem = tid + kPersistThreads * e;
+            for (int l = 0; l < P.tiles_per_wg && t_first + l < t_end; ++l) {
+                const TileMeta tm = P.meta[t_first + l];
+                if (rem < tm.nh) {
+                    double2 *xy = smem + (size_t)l * tile_words;
+                    hg[e] = P.halo_g[tm.hoff + rem];
+                    hloc[e] = l * tile_words + rem;
+                    xy[B + rem] = P.halo_xy[tm.hoff + rem];
+                    const double2 hb = P.bP[hg[e]];
+                    xy[2 * cap + rem] = make_double2(-hb.x, -hb.y);      // halo r
+                    xy[2 * cap + maxh + rem] = make_double2(0.0, 0.0); // halo p
+                    if (MG) { // a node another rank owns: its q comes through the window (slot s encoded as -2 - s)
+                        const int32_t hs = P.halo_qslot[tm.hoff + rem];
+                        if (hs >= 0) hg[e] = -2 - hs;
+                    }
+                    break;
+                }
+                rem -= tm.nh;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) acc[1] = 1.0; // "p.q" > 0: alpha finite, multiplies q = 0
+    persist_block_sum(acc, s_red);
+    int par = 0;
+    unsigned epoch = tag0; // the tags of successive exchanges
+    if (tid < 2) // the block sums are in every thread: two threads publish the record's two pieces
+        put_granules(P.recg + 4 * (2 * ((int64_t)par * gridDim.x + blockIdx.x) + tid), epoch,
+                     tid == 0 ? make_double2(acc[0], acc[1]) : make_double2(acc[2], acc[3]));
+    double2 hq[NH]; // q of this thread's halo nodes
+    if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec)
+           : !persist_exchange<NH>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk))
+        return;
+
+    const double c0 = P.c0, nu = P.nu, h = P.h;
+    double target = P.tol, bb = 0.0;
+    long long j = 0;
+    int verdict = 0; // 1 converged, 2 iteration cap, 3 non-finite
+    double cost = 0.0;
+    for (;;) {
+        const double S0 = s_S[0], S1 = s_S[1], S2 = s_S[2], S3 = s_S[3];
+        if (j == 0) {
+            bb = S0;
+            target = P.stop_mode == 2 ? P.tol * sqrt(bb) : P.tol;
+        }
+        const double rr = S0;
+        cost = P.stop_mode == 1 ? fabs(rr) : sqrt(rr);
+        const long long it_done = j - 1;
+        if (blockIdx.x == 0 && tid == 0 && it_done >= 1 && it_done - 1 < P.hist_len) P.hist[it_done - 1] = cost;
+        if (j == 0 && bb == 0.0) {
+            verdict = 1;
+            cost = 0.0;
+            break;
+        }
+        if (it_done >= 1 && cost <= target) verdict = 1;
+        else if (!(fabs(rr) <= 1.79769313486231570e308)) verdict = 3;
+        else if (it_done >= P.max_iter) verdict = 2;
+        if (verdict) break;
+        const double alpha = rr / S1;
+        const double beta = (rr + 2.0 * alpha * S2 + alpha * alpha * S3) / rr;
+
+        // ---- vector updates: r in registers, p and x in LDS, halo copies in LDS (their q from the publishers)
+#pragma unroll
+        for (int s = 0; s < NPT; ++s) {
+            if (!(flags[s] & 8)) continue;
+            double2 *xy = t_xy(s), *pim = xy + cap, *hr = pim + cap, *hp = hr + maxh, *xs = hp + maxh;
+            const double2 po = pim[lt];
+            double2 xo = xs[lt], pn;
+            xo.x += alpha * po.x;
+            xo.y += alpha * po.y;
+            xs[lt] = xo;
+            r[s].x += alpha * q[s].x;
+            r[s].y += alpha * q[s].y;
+            pn.x = -r[s].x + beta * po.x;
+            pn.y = -r[s].y + beta * po.y;
+            pim[lt] = pn;
+        }
+#pragma unroll
+        for (int e = 0; e < NH; ++e)
+            if (hg[e] != -1) {
+                double2 *hbase = smem + hloc[e]; // = tile base + position: coordinates at [B], p image at [cap + B], ...
+                double2 hrv = hbase[2 * cap], hpv = hbase[2 * cap + maxh];
+                hrv.x += alpha * hq[e].x;
+                hrv.y += alpha * hq[e].y;
+                hpv.x = -hrv.x + beta * hpv.x;
+                hpv.y = -hrv.y + beta * hpv.y;
+                hbase[2 * cap] = hrv;
+                hbase[2 * cap + maxh] = hpv;
+                hbase[cap + B] = hpv;
+            }
+        __syncthreads();
+
+        // ---- q = M K M p on the owned nodes, dot partials, publication
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = 0.0;
+#pragma unroll
+        for (int s = 0; s < NPT; ++s) {
+            if (!(flags[s] & 8)) continue;
+            const double2 *xy = t_xy(s), *pim = xy + cap;
+            const double2 ca = xy[lt], pa = pim[lt];
+            double fx = 0.0, fy = 0.0;
+            {
+                double2 rd = ca, ru = pa;
+                auto tri = [&](const double2 db, const double2 ub, const double2 dc, const double2 uc) {
+                    fan_force<double2, double>(db, ub, dc, uc, c0, nu, h, fx, fy);
+                };
+#pragma unroll
+                for (int k = 0; k < kPersistRegs; ++k) ring_word(w[s][k], xy, pim, ca, pa, rd, ru, tri);
+                for (int32_t k = kPersistRegs; k < deg[s]; ++k)
+                    ring_word(P.ell16[ell_off[s] + (int64_t)k * B], xy, pim, ca, pa, rd, ru, tri);
+            }
+            if ((flags[s] & 1) || !(flags[s] & 16)) fx = 0.0;
+            if ((flags[s] & 2) || !(flags[s] & 16)) fy = 0.0;
+            q[s] = make_double2(fx, fy);
+            if ((flags[s] & 20) == 20) put_granules(P.qg + 4 * ((int64_t)(par ^ 1) * P.N + node[s]), epoch + 1, q[s]);
+            if (MG && oslot[s] >= 0)
+                put_granules_sys(P.win_q + 4 * ((int64_t)(par ^ 1) * P.n_iface + oslot[s]), epoch + 1, q[s]);
+            acc[0] += r[s].x * r[s].x + r[s].y * r[s].y;
+            acc[1] += pa.x * fx + pa.y * fy;
+            acc[2] += r[s].x * fx + r[s].y * fy;
+            acc[3] += fx * fx + fy * fy;
+        }
+        persist_block_sum(acc, s_red);
+        par ^= 1;
+        ++epoch;
+        ++j;
+        if (tid < 2)
+            put_granules(P.recg + 4 * (2 * ((int64_t)par * gridDim.x + blockIdx.x) + tid), epoch,
+                         tid == 0 ? make_double2(acc[0], acc[1]) : make_double2(acc[2], acc[3]));
+        if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec)
+               : !persist_exchange<NH>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk))
+            return;
+    }
+    // x of iterate j-1 is in LDS; the verdict is the same in every workgroup
+#pragma unroll
+    for (int s = 0; s < NPT; ++s)
+        if ((flags[s] & 24) == 24) P.x[node[s]] = (t_xy(s) + 2 * cap + 2 * maxh)[lt];
+    if (blockIdx.x == 0 && tid == 0) {
+        FusedState *st = P.st;
+        st->bb = bb;
+        st->target = target;
+        st->iterations = j - 1 < 0 ? 0 : j - 1;
+        st->final_cost = cost;
+        st->converged = verdict == 1 ? 1 : 0;
+        st->breakdown = verdict == 3 ? 1 : 0;
+        st->done = 1;
+    }
+}
+
+int persist_tiles_per_wg(int32_t B) { return B == 256 || B == 512 ? kPersistNpt * (kPersistThreads / B) : 0; }
+
+size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh)
+{
+    const size_t tiles = (size_t)kPersistNpt * (kPersistThreads / B);
+    return tiles * (2 * (size_t)cap + 2 * (size_t)maxh + (size_t)B) * 16 + 2 * 256 * 16 +
+           (4 * (kPersistThreads / 64) + 4 + 4 * 32) * 8 + 16;
+}
+
+void persist_launch(const PersistParams &P, int32_t B, int32_t grid, hipStream_t s)
+{
+    const size_t lds = persist_lds_bytes(B, P.cap, P.maxh);
+    if (P.nranks > 1) {
+        if (B == 256)
+            k_cg_persist<256, true><<<grid, kPersistThreads, lds, s>>>(P);
+        else
+            k_cg_persist<512, true><<<grid, kPersistThreads, lds, s>>>(P);
+    } else if (B == 256)
+        k_cg_persist<256, false><<<grid, kPersistThreads, lds, s>>>(P);
+    else
+        k_cg_persist<512, false><<<grid, kPersistThreads, lds, s>>>(P);
+}
+
+// bit 2 of the node mask: some tile reads this node through its halo list, so its owner must publish q
+__global__ void __launch_bounds__(256) k_mark_published(const int32_t *halo_g, int64_t halo_total, uint8_t *maskP)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= halo_total) return;
+    // byte-wide atomic OR does not exist; neighbouring bytes belong to other nodes, so OR the containing word
+    const int64_t g = halo_g[i];
+    atomicOr((unsigned int *)(maskP + (g & ~(int64_t)3)), 4u << (8 * (g & 3)));
+}
+
+void mark_published(const int32_t *halo_g, int64_t halo_total, uint8_t *maskP, hipStream_t s)
+{
+    if (halo_total > 0) k_mark_published<<<(unsigned)((halo_total + 255) / 256), 256, 0, s>>>(halo_g, halo_total, maskP);
+}
+
+} // namespace magk
