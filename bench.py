@@ -101,10 +101,11 @@ def main():
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="world size 1 only: still create the nccl process group and the RCCL communicator and run "
                          "the distributed CG protocol (iteration kernel + one in-place all-reduce every iteration)")
-    ap.add_argument("--window", action="store_true",
-                    help="N > 1, EXPERIMENTAL: share a host-memory window so that every rank runs the on-chip CG and the "
-                         "per-iteration exchange goes through it (measured slower than one RCCL all-reduce per "
-                         "iteration once a rank has more than a few hundred interface nodes; default off)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "inboxes", "allreduce", "host-window"],
+                    help="N > 1: how the ranks exchange per CG iteration.  allreduce: streaming kernels + one RCCL "
+                         "all-reduce per iteration; inboxes: on-chip CG on every rank, exchange through per-rank "
+                         "inboxes in device memory (HIP IPC); auto (default): one untimed trial solve each way, the "
+                         "faster is kept; host-window: the inbox protocol through shared host memory (slow, for tests)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="REHEARSAL of the N > 1 code path on a one-GPU box: every rank drives GPU 0 and the collectives "
                          "go through gloo (host callback) instead of RCCL; the printed line is marked, it is no result")
@@ -150,27 +151,35 @@ def main():
     elif use_dist:
         ctx.init_rccl_from_torch(dist, rank, world)
     shm = None
-    if world > 1 and args.cg_variant == 2 and args.window:
-        # multi-GPU on-chip CG: a window of shared host memory for the per-iteration exchange (mag_comm_set_window)
+    exchange, autotune = ("RCCL all-reduce per iteration" if world > 1 else None), None
+    cpu_or_gpu = "cpu" if args.share_gpu else "cuda"
+
+    def all_agree(ok):
+        t_ok = torch.tensor([1 if ok else 0], dtype=torch.int32, device=cpu_or_gpu)
+        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
+        return int(t_ok.item()) == 1
+
+    if world > 1 and args.cg_variant == 2 and args.exchange == "host-window":
+        # EXPERIMENTAL: a window of shared host memory for the per-iteration exchange (mag_comm_set_window)
         from multiprocessing import shared_memory
         names = [None]
         if rank == 0:
             shm = shared_memory.SharedMemory(create=True, size=32 << 20)
             names[0] = shm.name
         dist.broadcast_object_list(names, src=0)
-        ok = 1
+        ok = True
         try:
             if rank != 0:
                 shm = shared_memory.SharedMemory(name=names[0])
                 from multiprocessing import resource_tracker
                 resource_tracker.unregister(shm._name, "shared_memory")  # rank 0 owns the segment (Python < 3.13)
             ctx.set_window(shm)
-        except Exception as exc:  # e.g. the runtime refuses to map the pages: every rank must then do without
-            print(f"rank {rank}: no host-memory window ({exc}); streaming kernels + RCCL", file=sys.stderr, flush=True)
-            ok = 0
-        t_ok = torch.tensor([ok], dtype=torch.int32, device="cpu" if args.share_gpu else "cuda")
-        dist.all_reduce(t_ok, op=dist.ReduceOp.MIN)
-        if int(t_ok.item()) == 0:
+        except Exception as exc:
+            print(f"rank {rank}: no host-memory window ({exc})", file=sys.stderr, flush=True)
+            ok = False
+        if all_agree(ok):
+            exchange = "host-memory window (granules)"
+        else:
             if ok:
                 ctx.set_window(None)
             if shm is not None:
@@ -184,6 +193,47 @@ def main():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def open_inboxes():
+        ok = True
+        try:
+            handles = [None] * world
+            dist.all_gather_object(handles, ctx.create_inbox(32 << 20))
+            ctx.open_inboxes(handles)
+        except Exception as exc:  # e.g. no peer mapping between two GPUs: every rank must then do without
+            print(f"rank {rank}: no device inboxes ({exc})", file=sys.stderr, flush=True)
+            ok = False
+        if not all_agree(ok):
+            if ok:
+                barrier()
+                ctx.close_inboxes()
+            return False
+        return True
+
+    def timed_solve():
+        barrier()
+        t_a = time.perf_counter()
+        ctx.run()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t_a], dtype=torch.float64, device=cpu_or_gpu)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    if world > 1 and args.cg_variant == 2 and args.exchange in ("auto", "inboxes"):
+        # Multi-GPU on-chip CG: every rank runs its share as one persistent launch and the per-iteration exchange goes
+        # through per-rank inboxes in device memory (HIP IPC over xGMI) instead of a collective.  It cannot be
+        # measured on the one-GPU development box, so the choice is made HERE, before anything is timed: one solve to
+        # warm up and one timed solve each way, the faster exchange is kept (every rank sees the same two numbers).
+        if open_inboxes():
+            ctx.run()
+            t_inbox, k_inbox = timed_solve(), int(ctx.stats()["cg_kernel"])
+            barrier()
+            ctx.close_inboxes()
+            ctx.run()
+            t_rccl = timed_solve()
+            autotune = {"s_per_solve_inboxes": t_inbox, "kernel_with_inboxes": k_inbox, "s_per_solve_allreduce": t_rccl}
+            if (args.exchange == "inboxes" or t_inbox < t_rccl) and k_inbox == 2 and open_inboxes():
+                exchange = "per-rank inboxes in device memory (HIP IPC), on-chip CG on every rank"
 
     for _ in range(args.warmup):
         ctx.run()
@@ -244,8 +294,7 @@ def main():
                                    f"right edge ux=delta; full solver::run per step; CG stop={args.stop} tol={args.tol:g}",
                        "elements": E, "nodes": N, "tile_nodes": args.tile, "cg_variant": args.cg_variant, "cg_kernel": kind, "cg_stop": args.stop, "cg_tol": args.tol,
                        "parallelism": f"strips{world}" if world > 1 else "single",
-                       "exchange": (("host-memory window (granules)" if kind == 2 else "RCCL all-reduce per iteration")
-                                    if world > 1 else None)},
+                       "exchange": exchange, "exchange_autotune": autotune},
             "roofline": {"bound": "hbm",
                          "kernel": {2: "k_cg_persist<%d> (the whole CG solve in one launch: state resident in registers "
                                        "and LDS, grid-wide exchange by tagged granules every iteration)" % args.tile,
@@ -286,6 +335,8 @@ def main():
 
     if shm is not None:
         ctx.set_window(None)
+    if world > 1:
+        barrier()  # nobody frees an inbox another rank's kernel may still touch
     ctx.close()
     if shm is not None:
         barrier()

@@ -232,6 +232,15 @@ int mag_comm_init_callback(mag_ctx *ctx, int32_t nranks, int32_t rank, mag_allre
  * agree on a fallback and to assemble the solution.  Without a window, or when the mesh does not fit the chips, the
  * streaming kernels + one all-reduce per iteration run.  NULL / 0 removes the window. */
 int mag_comm_set_window(mag_ctx *ctx, void *host_ptr, uint64_t bytes);
+/* The same protocol with the window where it belongs: one INBOX per rank in that rank's device memory, mapped by the
+ * other ranks through HIP IPC.  A rank only reads its own inbox (polls stay in local HBM); writers store into the
+ * inboxes of the ranks that read a value (across xGMI).  Every rank: mag_comm_inbox_create(ctx, bytes, handle) (bytes
+ * as for the window; `handle` receives MAG_IPC_HANDLE_BYTES bytes), exchange the handles by any means, then
+ * mag_comm_inbox_open(ctx, all_handles) with the nranks handles in rank order.  bytes = 0 removes the inboxes.
+ * EXPERIMENTAL: exercised with several ranks on one GPU only. */
+#define MAG_IPC_HANDLE_BYTES 64
+int mag_comm_inbox_create(mag_ctx *ctx, uint64_t bytes, void *handle_out);
+int mag_comm_inbox_open(mag_ctx *ctx, const void *handles);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,7 @@ MAG_STOP_RNORM, MAG_STOP_RNORM_SQ, MAG_STOP_REL = 0, 1, 2
 MAG_OP_MATRIX_FREE, MAG_OP_CSR = 0, 1
 MAG_MEM_HOST, MAG_MEM_DEVICE = 0, 1
 MAG_UNIQUE_ID_BYTES = 128
+MAG_IPC_HANDLE_BYTES = 64
 
 # every symbol include/magnetite_hip.h declares (tests/test_abi.py checks the .so exports them all)
 SYMBOLS = [
@@ -25,7 +26,7 @@ SYMBOLS = [
     "mag_upload", "mag_run", "mag_download", "mag_get_stats", "mag_get_history", "mag_compute_element_area",
     "mag_compute_strain_displacement_matrix", "mag_compute_stress_strain_matrix",
     "mag_element_stiffness", "mag_assemble_csr", "mag_reduce_system", "mag_apply_operator", "mag_time_operator", "mag_time_spmv",
-    "mag_comm_get_unique_id", "mag_comm_init_rccl", "mag_comm_init_callback", "mag_comm_set_window",
+    "mag_comm_get_unique_id", "mag_comm_init_rccl", "mag_comm_init_callback", "mag_comm_set_window", "mag_comm_inbox_create", "mag_comm_inbox_open",
 ]
 
 
@@ -115,6 +116,8 @@ def lib():
     L.mag_comm_init_rccl.argtypes = [vp, vp, C.c_int32, C.c_int32]
     L.mag_comm_init_callback.argtypes = [vp, C.c_int32, C.c_int32, ALLREDUCE_FN, vp]
     L.mag_comm_set_window.argtypes = [vp, vp, C.c_uint64]
+    L.mag_comm_inbox_create.argtypes = [vp, C.c_uint64, vp]
+    L.mag_comm_inbox_open.argtypes = [vp, vp]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("mag_version",):

@@ -118,6 +118,11 @@ struct mag_ctx {
     // multi-GPU on-chip CG: a window of host memory mapped by every rank (mag_comm_set_window)
     void *win_host = nullptr, *win_dev = nullptr;
     size_t win_bytes = 0;
+    // ... or, better, one inbox per rank in DEVICE memory, IPC-mapped by the others (mag_comm_inbox_*)
+    void *inbox_own = nullptr, *inbox_peer[8] = {};
+    size_t inbox_bytes = 0;
+    bool inbox_ready = false;
+    DevBuf iface_readers;
     uint32_t solve_seq = 0;
     int nsums() const { return pre ? 5 : 4; }
     DevBuf xy32, hxy32, rqp32a, rqp32b, x32; // fp32 leg (mag_options.precision = 1)
@@ -218,7 +223,8 @@ int ensure_order(mag_ctx *ctx)
     // (measured: 100k triangles 6.6 vs 7.7 us per iteration; 1M triangles 22.0 vs 20.4)
     // (since the on-chip CG exists, 512-node tiles also win on mid-size meshes it can hold: 6.2 / 6.4 / 8.3 us per
     // iteration at 59k / 121k / 245k nodes against 6.9 / 8.8 / 13.8 with streamed 256-node tiles)
-    const bool on_chip_candidate = ctx->opt.cg_variant == 2 && (ctx->comm.nranks == 1 || ctx->win_dev != nullptr) &&
+    const bool on_chip_candidate = ctx->opt.cg_variant == 2 &&
+                                   (ctx->comm.nranks == 1 || ctx->win_dev != nullptr || ctx->inbox_ready) &&
                                    getenv("MAG_TUNE_FORCE_DIST") == nullptr && ctx->opt.precision == 0 &&
                                    ctx->opt.preconditioner == 0 && ctx->opt.cg_operator == MAG_OP_MATRIX_FREE &&
                                    ctx->opt.op_variant != 1 && !ctx->persist_failed;
@@ -350,20 +356,33 @@ int ensure_order(mag_ctx *ctx)
                 HIPCHK(hipMemcpyAsync(hg.data(), ctx->halo_g.p, 4 * (size_t)ctx->halo_total, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             std::vector<int32_t> iface;
+            std::vector<std::pair<int32_t, int32_t>> reads; // (node, reading rank)
             for (int r_ = 0; r_ < R; ++r_) {
                 const int64_t lo = std::min<int64_t>((int64_t)tile_lo(r_) * B, N);
                 const int64_t hi = std::min<int64_t>((int64_t)tile_lo(r_ + 1) * B, N);
                 for (int32_t t = tile_lo(r_); t < tile_lo(r_ + 1); ++t)
                     for (int32_t k = hoff[t]; k < hoff[t + 1]; ++k)
-                        if (hg[k] < lo || hg[k] >= hi) iface.push_back(hg[k]);
+                        if (hg[k] < lo || hg[k] >= hi) {
+                            iface.push_back(hg[k]);
+                            reads.emplace_back(hg[k], r_);
+                        }
             }
             std::sort(iface.begin(), iface.end());
             iface.erase(std::unique(iface.begin(), iface.end()), iface.end());
             ctx->n_iface = (int32_t)iface.size();
+            // which ranks read each interface node (on-chip multi-GPU CG: its owner stores q into their inboxes)
+            std::vector<uint8_t> readers(iface.size() + 1, 0);
+            for (const auto &pr : reads) {
+                const size_t slot = std::lower_bound(iface.begin(), iface.end(), pr.first) - iface.begin();
+                readers[slot] |= (uint8_t)(1u << (pr.second & 7));
+            }
             HIPCHK(ctx->iface.reserve(4 * (iface.size() + 1)));
-            if (!iface.empty())
+            HIPCHK(ctx->iface_readers.reserve(iface.size() + 16));
+            if (!iface.empty()) {
                 HIPCHK(hipMemcpyAsync(ctx->iface.p, iface.data(), 4 * iface.size(), hipMemcpyHostToDevice, s));
-            HIPCHK(hipStreamSynchronize(s)); // iface (host vector) must outlive the copy
+                HIPCHK(hipMemcpyAsync(ctx->iface_readers.p, readers.data(), iface.size(), hipMemcpyHostToDevice, s));
+            }
+            HIPCHK(hipStreamSynchronize(s)); // the host vectors must outlive the copies
         }
         HIPCHK(ctx->comm_pq.reserve(64));
         HIPCHK(ctx->comm_rr.reserve(8 * (1 + 2 * (size_t)ctx->n_iface) + 64));
@@ -402,7 +421,9 @@ int ensure_order(mag_ctx *ctx)
     const bool forced_dist = ctx->dist && !mg; // single-rank rehearsal of the distributed protocol: streaming kernels
     if (ctx->opt.cg_variant == 2 && ctx->use_lds && !forced_dist && !ctx->persist_failed && ctx->opt.precision == 0 &&
         ctx->opt.preconditioner == 0 && ctx->opt.cg_operator == MAG_OP_MATRIX_FREE &&
-        (!mg || (ctx->win_dev != nullptr && ctx->win_bytes >= 64 + 128 * (size_t)R + 64 * (size_t)ctx->n_iface))) {
+        (!mg || R > 8 ||
+         ((ctx->inbox_ready ? ctx->inbox_bytes : (ctx->win_dev ? ctx->win_bytes : 0)) >=
+          64 + 128 * (size_t)R + 64 * (size_t)ctx->n_iface)) && R <= 8) {
         int dev = 0, cus = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -983,7 +1004,6 @@ int cg_phase_persist(mag_ctx *ctx)
         // same solves), so nothing of an earlier solve can look current.  4096 solves share 12 bits.
         ctx->solve_seq = (ctx->solve_seq + 1) & 0xfffu;
         if (ctx->solve_seq == 0) ctx->solve_seq = 1;
-        uint8_t *w = (uint8_t *)ctx->win_dev;
         P.t0 = ctx->t0;
         P.t1 = ctx->t1;
         P.rank = ctx->comm.rank;
@@ -992,9 +1012,10 @@ int cg_phase_persist(mag_ctx *ctx)
         P.tag_base = ctx->solve_seq << 20;
         P.own_qslot = ctx->own_qslot.as<int32_t>();
         P.halo_qslot = ctx->halo_qslot.as<int32_t>();
-        P.win_tmo = (uint32_t *)w;
-        P.win_rec = (unsigned long long *)(w + 64);
-        P.win_q = (unsigned long long *)(w + 64 + 128 * (size_t)R);
+        P.win_shared = ctx->inbox_ready ? 0 : 1;
+        for (int r = 0; r < R; ++r)
+            P.inbox[r] = (uint8_t *)(ctx->inbox_ready ? ctx->inbox_peer[r] : ctx->win_dev);
+        P.iface_readers = ctx->iface_readers.as<uint8_t>();
         P.grec = ctx->grec.as<unsigned long long>();
     }
     P.N = ctx->N;
@@ -1048,7 +1069,12 @@ int cg_phase_persist(mag_ctx *ctx)
         HIPCHK(hipMemcpyAsync(&flag, ctx->comm_pq.p, 8, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         failed = flag != 0.0;
-        if (failed) *(volatile uint32_t *)ctx->win_host = 0; // the window's timeout word, for the next context
+        if (failed) { // the timeout word, for the next context
+            if (ctx->inbox_ready)
+                HIPCHK(hipMemsetAsync(ctx->inbox_own, 0, 64, s));
+            else
+                *(volatile uint32_t *)ctx->win_host = 0;
+        }
     }
     if (failed) {
         // a workgroup gave up waiting at the grid barrier (not every workgroup resident: the GPU is shared with
@@ -1333,6 +1359,18 @@ mag_ctx *mag_create(const mag_options *opt)
     return ctx;
 }
 
+static void inbox_release(mag_ctx *ctx)
+{
+    for (int r = 0; r < 8; ++r) {
+        if (ctx->inbox_peer[r] && ctx->inbox_peer[r] != ctx->inbox_own) (void)hipIpcCloseMemHandle(ctx->inbox_peer[r]);
+        ctx->inbox_peer[r] = nullptr;
+    }
+    if (ctx->inbox_own) (void)hipFree(ctx->inbox_own);
+    ctx->inbox_own = nullptr;
+    ctx->inbox_bytes = 0;
+    ctx->inbox_ready = false;
+}
+
 void mag_destroy(mag_ctx *ctx)
 {
     if (!ctx) return;
@@ -1341,6 +1379,7 @@ void mag_destroy(mag_ctx *ctx)
         (void)hipStreamSynchronize(ctx->stream);
         ctx->comm.destroy();
         if (ctx->win_host) (void)hipHostUnregister(ctx->win_host);
+        inbox_release(ctx);
         if (ctx->graph) (void)hipGraphExecDestroy(ctx->graph);
         if (ctx->h_state) (void)hipHostFree(ctx->h_state);
         if (ctx->h_fstate) (void)hipHostFree(ctx->h_fstate);
@@ -1762,6 +1801,51 @@ int mag_comm_set_window(mag_ctx *ctx, void *host_ptr, uint64_t bytes)
     ctx->win_host = host_ptr;
     ctx->win_dev = dev;
     ctx->win_bytes = (size_t)bytes;
+    return MAG_OK;
+}
+
+int mag_comm_inbox_create(mag_ctx *ctx, uint64_t bytes, void *handle_out)
+{
+    if (int rc = enter(ctx)) return rc;
+    inbox_release(ctx);
+    if (bytes == 0) return MAG_OK; // inboxes removed
+    if (bytes < 4096 || !handle_out) return fail(ctx, MAG_ERR_BAD_ARGS, "inbox: %llu bytes / null handle", (unsigned long long)bytes);
+    static_assert(sizeof(hipIpcMemHandle_t) == MAG_IPC_HANDLE_BYTES, "ipc handle size");
+    // fine-grained: other GPUs' stores must become visible to this GPU's running kernel
+    HIPCHK(hipExtMallocWithFlags(&ctx->inbox_own, (size_t)bytes, hipDeviceMallocFinegrained));
+    HIPCHK(hipMemset(ctx->inbox_own, 0, (size_t)bytes));
+    hipIpcMemHandle_t h;
+    const hipError_t e = hipIpcGetMemHandle(&h, ctx->inbox_own);
+    if (e != hipSuccess) {
+        inbox_release(ctx);
+        return fail(ctx, MAG_ERR_HIP, "hipIpcGetMemHandle failed: %s", hipGetErrorString(e));
+    }
+    memcpy(handle_out, &h, sizeof h);
+    ctx->inbox_bytes = (size_t)bytes;
+    return MAG_OK;
+}
+
+int mag_comm_inbox_open(mag_ctx *ctx, const void *handles)
+{
+    if (int rc = enter(ctx)) return rc;
+    const int R = ctx->comm.nranks, me = ctx->comm.rank;
+    if (!ctx->inbox_own || !handles || R < 2 || R > 8)
+        return fail(ctx, MAG_ERR_STATE, "inbox_open needs mag_comm_inbox_create, a communicator of 2..8 ranks and the handles");
+    for (int r = 0; r < R; ++r) {
+        if (r == me) {
+            ctx->inbox_peer[r] = ctx->inbox_own;
+            continue;
+        }
+        hipIpcMemHandle_t h;
+        memcpy(&h, (const uint8_t *)handles + (size_t)r * sizeof h, sizeof h);
+        const hipError_t e = hipIpcOpenMemHandle(&ctx->inbox_peer[r], h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            ctx->inbox_peer[r] = nullptr;
+            inbox_release(ctx);
+            return fail(ctx, MAG_ERR_HIP, "hipIpcOpenMemHandle (rank %d) failed: %s", r, hipGetErrorString(e));
+        }
+    }
+    ctx->inbox_ready = true;
     return MAG_OK;
 }
 

@@ -298,9 +298,14 @@ struct PersistParams {
     uint32_t tag_base;          // solve sequence << 20
     const int32_t *own_qslot;   // N: interface slot of an owned node other ranks read, -1 otherwise
     const int32_t *halo_qslot;  // halo_total: interface slot of a halo entry another rank owns, -1 otherwise
-    unsigned long long *win_rec; // window: 2 * nranks * 8 granules
-    unsigned long long *win_q;   // window: 2 * n_iface * 4 granules
-    uint32_t *win_tmo;           // window: timeout word
+    // The window, seen as one INBOX per rank (layout of each: 64 bytes {timeout word}, 2 * nranks * 8 record granules,
+    // 2 * n_iface * 4 q granules).  A rank only ever reads its own inbox; writers store into the inbox of every rank
+    // that reads the value.  Host-memory window: all inbox pointers are the same shared pages (win_shared = 1, one
+    // store serves everybody).  Peer window: inbox[r] is rank r's device memory, IPC-mapped (stores cross xGMI, polls
+    // stay in local HBM).
+    uint8_t *inbox[8];
+    int32_t win_shared;
+    const uint8_t *iface_readers; // n_iface: bit r set when rank r reads the interface node of that slot
     unsigned long long *grec;    // device: 2 * 8 granules, the grid-wide sums republished by workgroup 0
 };
 int persist_tiles_per_wg(int32_t B); // tiles one workgroup keeps on chip (0: tile size not supported)

@@ -177,6 +177,19 @@ __device__ inline bool get_granules_sys(const unsigned long long *base, uint32_t
     return ok;
 }
 
+// q of an interface node this rank owns, into the inbox of every rank that reads it
+__device__ inline void publish_q(const PersistParams &P, int par, int32_t slot, unsigned tag, double2 v)
+{
+    const size_t off = 64 + 128 * (size_t)P.nranks + 32 * ((size_t)par * P.n_iface + slot);
+    if (P.win_shared) {
+        put_granules_sys((unsigned long long *)(P.inbox[0] + off), tag, v);
+        return;
+    }
+    const uint32_t readers = P.iface_readers[slot];
+    for (int r = 0; r < P.nranks; ++r)
+        if ((readers >> r) & 1u) put_granules_sys((unsigned long long *)(P.inbox[r] + off), tag, v);
+}
+
 // Exchange of the multi-GPU kernel.  Halo q: from this GPU's granules, or from the window when another rank owns the
 // node (hg < 0 encodes the interface slot as -2 - slot).  Sums: workgroup 0 gathers this rank's records, publishes
 // their sum in the window, gathers every rank's record there, sums them in rank order and republishes the result on
@@ -189,10 +202,13 @@ __device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsi
     const int tid = threadIdx.x;
     const int grid = gridDim.x, R = P.nranks;
     gu32 *tmo = (gu32 *)P.sync + 9;
-    gu32 *wtmo = (gu32 *)P.win_tmo;
+    uint8_t *mine = P.inbox[P.rank]; // this rank's inbox: the only one it reads
+    gu32 *wtmo = (gu32 *)mine;
+    auto inbox_rec = [&](int r) { return (unsigned long long *)(P.inbox[r] + 64); };
     const unsigned long long *recb = P.recg + 8 * (int64_t)par * grid;
     const unsigned long long *qbase = P.qg + 4 * (int64_t)par * P.N;
-    const unsigned long long *wq = P.win_q + 4 * (int64_t)par * P.n_iface;
+    const unsigned long long *wq =
+        (const unsigned long long *)(mine + 64 + 128 * (size_t)R) + 4 * (int64_t)par * P.n_iface;
     const bool lead = blockIdx.x == 0;
     bool have_h[NH];
 #pragma unroll
@@ -208,10 +224,9 @@ __device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsi
         return __syncthreads_or(dead) != 0;
     };
     auto fail = [&]() {
-        if (tid == 0) {
-            __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(wtmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        if (tid == 0) __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < (P.win_shared ? 1 : R)) // tell every rank
+            __hip_atomic_store((gu32 *)P.inbox[tid], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return false;
     };
     // Window reads cross PCIe: they are issued only once the grid-wide sums are known -- every rank wrote its q before
@@ -272,10 +287,10 @@ __device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsi
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) S[c] = wave_sum_dpp(S[c]);
-            // (2) this rank's sums into the window
-            if (tid < 2)
-                put_granules_sys(P.win_rec + 4 * (2 * ((int64_t)par * R + P.rank) + tid), tag,
-                                 tid == 0 ? make_double2(S[0], S[1]) : make_double2(S[2], S[3]));
+            // (2) this rank's sums into every rank's inbox (two pieces each; one store serves all in a shared window)
+            if (tid < 2 * (P.win_shared ? 1 : R))
+                put_granules_sys(inbox_rec(tid >> 1) + 4 * (2 * ((int64_t)par * R + P.rank) + (tid & 1)), tag,
+                                 (tid & 1) == 0 ? make_double2(S[0], S[1]) : make_double2(S[2], S[3]));
         }
         __syncthreads();
         // (3) every rank's sums from the window
@@ -284,7 +299,8 @@ __device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsi
         for (; spins < P.spin_limit; ++spins) {
             if (!have_w) {
                 double2 v;
-                have_w = get_granules_sys(P.win_rec + 8 * (int64_t)par * R, 64u * (uint32_t)R, 32u * (uint32_t)tid, tag, v);
+                have_w = get_granules_sys(inbox_rec(P.rank) + 8 * (int64_t)par * R, 64u * (uint32_t)R, 32u * (uint32_t)tid,
+                                          tag, v);
                 if (have_w) s_rec[tid] = v;
             }
             if (__syncthreads_and(have_w ? 1 : 0)) {
@@ -422,7 +438,7 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
         if ((flags[s] & 20) == 20) put_granules(P.qg + 4 * nd, tag0, make_double2(0.0, 0.0)); // q_{-1} = 0, parity 0
         if (MG && (flags[s] & 16)) {
             oslot[s] = P.own_qslot[nd];
-            if (oslot[s] >= 0) put_granules_sys(P.win_q + 4 * (int64_t)oslot[s], tag0, make_double2(0.0, 0.0));
+            if (oslot[s] >= 0) publish_q(P, 0, oslot[s], tag0, make_double2(0.0, 0.0));
         }
     }
     // halo entries of the workgroup's tiles, in tile order, dealt out round-robin: thread t takes entries t, t + 512
@@ -547,7 +563,7 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
             q[s] = make_double2(fx, fy);
             if ((flags[s] & 20) == 20) put_granules(P.qg + 4 * ((int64_t)(par ^ 1) * P.N + node[s]), epoch + 1, q[s]);
             if (MG && oslot[s] >= 0)
-                put_granules_sys(P.win_q + 4 * ((int64_t)(par ^ 1) * P.n_iface + oslot[s]), epoch + 1, q[s]);
+                publish_q(P, par ^ 1, oslot[s], epoch + 1, q[s]);
             acc[0] += r[s].x * r[s].x + r[s].y * r[s].y;
             acc[1] += pa.x * fx + pa.y * fy;
             acc[2] += r[s].x * fx + r[s].y * fy;

@@ -140,6 +140,21 @@ class Context:
         self._check(self._L.mag_comm_set_window(self._h, C.c_void_p(addr), shm.size))
         self._window = shm  # keep the mapping alive as long as the library uses it
 
+    def create_inbox(self, nbytes=8 << 20):
+        """Multi-GPU on-chip CG, peer-memory form: allocates this rank's inbox in device memory and returns its HIP IPC
+        handle (bytes); exchange the handles of all ranks and pass them, in rank order, to open_inboxes()."""
+        h = (C.c_uint8 * _lib.MAG_IPC_HANDLE_BYTES)()
+        self._check(self._L.mag_comm_inbox_create(self._h, nbytes, C.cast(h, C.c_void_p)))
+        return bytes(h)
+
+    def open_inboxes(self, handles):
+        raw = b"".join(handles)
+        buf = (C.c_uint8 * len(raw)).from_buffer_copy(raw)
+        self._check(self._L.mag_comm_inbox_open(self._h, C.cast(buf, C.c_void_p)))
+
+    def close_inboxes(self):
+        self._check(self._L.mag_comm_inbox_create(self._h, 0, None))
+
     def init_callback(self, fn, rank, world):
         """Test transport: fn(numpy_view) must sum the array over ranks in place (e.g. gloo all_reduce)."""
         import numpy as _np

@@ -24,7 +24,9 @@ def main():
     ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--tile", type=int, default=256)
     ap.add_argument("--precond", type=int, default=0, help="mag_options.preconditioner (checked against the oracle's PCG)")
-    ap.add_argument("--window", type=int, default=0, help="1: share a host-memory window (on-chip CG on every rank)")
+    ap.add_argument("--window", type=int, default=0,
+                    help="on-chip CG on every rank: 1 = exchange through a shared host-memory window, 2 = through "
+                         "per-rank inboxes in device memory (HIP IPC)")
     ap.add_argument("--stacked", type=int, default=0, help="bench.py's weak-scaling geometry: plate-with-hole stacked N times")
     a = ap.parse_args()
     import torch
@@ -55,7 +57,7 @@ def main():
             dist.all_reduce(t)
 
         shm = None
-        if a.window:
+        if a.window == 1:
             from multiprocessing import shared_memory
             names = [None]
             if rank == 0:
@@ -70,6 +72,10 @@ def main():
             c.init_callback(allreduce, rank, world)
             if shm is not None:
                 c.set_window(shm)
+            if a.window == 2:
+                handles = [None] * world
+                dist.all_gather_object(handles, c.create_inbox())
+                c.open_inboxes(handles)
             out = c.solve(prob)
             kernel = c.stats()["cg_kernel"]
             if a.window:
@@ -77,14 +83,19 @@ def main():
                       f"{c.stats()['ms_cg'] * 1e3 / max(1, out['iterations']):.2f} us per iteration", flush=True)
                 out2 = c.solve(prob)                       # a second solve: new tags, same window
                 assert np.array_equal(out2["u"], out["u"]) and c.stats()["cg_kernel"] == kernel
-                c.set_window(None)
+                if a.window == 1:
+                    c.set_window(None)
+                else:
+                    dist.barrier()          # nobody closes an inbox another rank's kernel may still touch
+                    c.close_inboxes()
         if a.window:
             print(f"rank {rank}: cg_kernel {kernel}", flush=True)
             assert kernel == 2, kernel
             dist.barrier()
-            shm.close()
-            if rank == 0:
-                shm.unlink()
+            if shm is not None:
+                shm.close()
+                if rank == 0:
+                    shm.unlink()
     ref = oracle.run(prob.xy_flat, prob.conn_flat, prob.u_known, prob.u_in, prob.f_in, prob.youngs_modulus,
                      prob.poisson_ratio, prob.part_thickness, path="sparse", precond=a.precond)
     err = np.linalg.norm(out["u"] - ref["u"]) / np.linalg.norm(ref["u"])

@@ -32,6 +32,16 @@ def test_four_ranks_on_the_weak_scaling_geometry(built):
 
 
 @pytest.mark.parametrize("nproc", [2, 3])
+def test_on_chip_cg_across_ranks_through_device_inboxes(built, nproc):
+    """The same protocol with one inbox per rank in DEVICE memory, mapped by the other ranks through HIP IPC: a rank
+    polls only its own inbox, writers store into the inboxes of the ranks that read a value.  (Here the ranks share
+    one GPU, so the IPC mappings are same-device; on a node the stores cross xGMI.)"""
+    r = launch(nproc, "callback", 29587 + nproc, 1, ("--window", "2", "--tile", "512", "--mesh", "120"),
+               {"MAG_TUNE_PERSIST_MIN_K": "1"})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("nproc", [2, 3])
 def test_on_chip_cg_across_ranks_through_a_host_window(built, nproc):
     """Every rank runs its share of the mesh as one persistent launch; per iteration the ranks exchange one record of
     sums and the q of the interface nodes through a window of shared host memory (tagged granules, system scope).  On

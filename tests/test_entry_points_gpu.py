@@ -36,15 +36,15 @@ def test_bench_prints_one_contract_line(built):
     assert d["value"] > 10.0 * cb["value"]          # north_star: >= 10x the CPU solver at 1 GPU
 
 
-@pytest.mark.parametrize("window", [False, True], ids=["rccl-path", "host-window"])
+@pytest.mark.parametrize("window", ["allreduce", "auto", "host-window"])
 def test_bench_multi_rank_code_path_on_one_gpu(built, window):
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed with both
     ranks on the one GPU and gloo in place of RCCL (--share-gpu): stacked weak-scaling mesh, barriers, max-over-ranks
     timing, rank 0 prints the single line."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-           "127.0.0.1", "--master-port", str(29581 + (1 if window else 0)), os.path.join(ROOT, "bench.py"), "--gpus", "2",
-           "--share-gpu", "--workload", "plate100k", "--steps", "1", "--warmup", "1", "--op-reps", "20"] + \
-          (["--window"] if window else [])
+           "127.0.0.1", "--master-port", str(29581 + len(window)), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--share-gpu", "--workload", "plate100k", "--steps", "1", "--warmup", "1", "--op-reps", "20",
+           "--exchange", window]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
@@ -54,10 +54,16 @@ def test_bench_multi_rank_code_path_on_one_gpu(built, window):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None and "rehearsal" in d
     assert d["config"]["parallelism"] == "strips2" and d["config"]["elements"] == 2 * 100352
     assert d["cg_converged"] == 1 and d["value"] > 0
-    if window:  # two ranks x ~50 workgroups fit the one GPU side by side: the multi-GPU on-chip CG runs
+    if window == "host-window":  # two ranks x ~50 workgroups fit the one GPU side by side: the on-chip CG runs
         assert d["config"]["cg_kernel"] == 2 and "window" in d["config"]["exchange"]
-    else:       # default: streaming kernels, one all-reduce per iteration
-        assert d["config"]["cg_kernel"] == 1
+    elif window == "allreduce":  # streaming kernels, one all-reduce per iteration
+        assert d["config"]["cg_kernel"] == 1 and "all-reduce" in d["config"]["exchange"]
+    else:                        # default: one untimed trial each way, the faster kept
+        tune = d["config"]["exchange_autotune"]
+        assert tune["kernel_with_inboxes"] == 2 and tune["s_per_solve_inboxes"] > 0 and tune["s_per_solve_allreduce"] > 0
+        faster = tune["s_per_solve_inboxes"] < tune["s_per_solve_allreduce"]
+        assert d["config"]["cg_kernel"] == (2 if faster else 1)
+        assert ("inboxes" in d["config"]["exchange"]) == faster
 
 
 def test_smoke_entry_point(built):
