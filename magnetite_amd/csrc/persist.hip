@@ -31,14 +31,17 @@ constexpr int kPersistThreads = 512; // 8 waves per CU = 2 per SIMD: 256 VGPRs p
 // next record first).
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 
+// Two 16-byte write-through stores carry the four granules of a value; each 8-byte granule is naturally aligned inside
+// its store, so a reader sees every granule whole (and validates each by its tag).
 __device__ inline void put_granules(unsigned long long *g, unsigned epoch, double2 v)
 {
     unsigned w[4];
     __builtin_memcpy(w, &v, 16);
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        __hip_atomic_store((gu64 *)g + k, ((unsigned long long)epoch << 32) | w[k], __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+    const u32x4 a = {w[0], epoch, w[1], epoch}, b = {w[2], epoch, w[3], epoch};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1\n\ts_nop 1"
+                 :
+                 : "v"(g), "v"(a), "v"(b)
+                 : "memory");
 }
 
 // Four granules (32 bytes) by two 16-byte sc1 loads: each 8-byte granule was written by one atomic store and validates
@@ -158,10 +161,11 @@ __device__ inline void put_granules_sys(unsigned long long *g, unsigned tag, dou
 {
     unsigned w[4];
     __builtin_memcpy(w, &v, 16);
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        __hip_atomic_store((gu64 *)g + k, ((unsigned long long)tag << 32) | w[k], __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
+    const u32x4 a = {w[0], tag, w[1], tag}, b = {w[2], tag, w[3], tag};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0 sc1\n\ts_nop 1"
+                 :
+                 : "v"(g), "v"(a), "v"(b)
+                 : "memory");
 }
 
 // `base` wave-uniform, as for get_granules; sc0 | sc1 = system scope: the loads go to the host memory itself.
