@@ -111,7 +111,7 @@ struct mag_ctx {
     int32_t g_all = 1; // ... of the rank with the most tiles: dot-partial slots of the exchange buffer (multi-GPU)
     size_t cwords = 0; // doubles per exchange buffer: nsums * g_all + 2 * n_iface
     bool pre = false;  // mag_options.preconditioner != 0
-    // on-chip CG (cg.hip, k_cg_persist): the whole solve in one launch when every tile fits registers + LDS
+    // on-chip CG (persist.hip, k_cg_persist): the whole solve in one launch when every tile fits registers + LDS
     bool persist = false, persist_failed = false;
     int32_t persist_k = 0, persist_grid = 0, persist_maxh = 0, cg_kernel = 0;
     DevBuf qx, wg_part, psync, grec; // published-q granules, partial-record granules, timeout word, republished sums
@@ -972,7 +972,7 @@ int cg_phase_fused(mag_ctx *ctx)
     return MAG_OK;
 }
 
-// ---- on-chip variant: ONE launch for the whole solve (cg.hip, k_cg_persist) ----
+// ---- on-chip variant: ONE launch for the whole solve (persist.hip, k_cg_persist) ----
 int cg_phase_persist(mag_ctx *ctx)
 {
     using magk::FusedState;

@@ -270,7 +270,7 @@ void fused_setup(const double *part, int32_t nPart, int32_t stride, int stop_mod
 void comm_slots(const int32_t *iface, int32_t n_iface, int32_t own0, int32_t own1, const int32_t *halo_g,
                 int64_t halo_total, int64_t N, int32_t *own_qslot, int32_t *halo_qslot, hipStream_t s);
 
-// ---- on-chip (persistent) CG: the whole solve in one launch when every tile fits registers + LDS (cg.hip) ----
+// ---- on-chip (persistent) CG: the whole solve in one launch when every tile fits registers + LDS (persist.hip) ----
 struct PersistParams {
     int64_t N;
     int32_t T, tiles_per_wg, cap, maxh, hist_len, stop_mode;
