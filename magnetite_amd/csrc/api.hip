@@ -421,6 +421,8 @@ int ensure_order(mag_ctx *ctx)
     const bool forced_dist = ctx->dist && !mg; // single-rank rehearsal of the distributed protocol: streaming kernels
     if (ctx->opt.cg_variant == 2 && ctx->use_lds && !forced_dist && !ctx->persist_failed && ctx->opt.precision == 0 &&
         ctx->opt.preconditioner == 0 && ctx->opt.cg_operator == MAG_OP_MATRIX_FREE &&
+        // the granule tags count the iterations: 32 bits on one GPU, 24 bits next to the solve sequence across GPUs
+        ctx->opt.max_iter < (mg ? (int64_t(1) << 24) - 4 : (int64_t(1) << 31) - 4) &&
         (!mg || R > 8 ||
          ((ctx->inbox_ready ? ctx->inbox_bytes : (ctx->win_dev ? ctx->win_bytes : 0)) >=
           64 + 128 * (size_t)R + 64 * (size_t)ctx->n_iface)) && R <= 8) {
@@ -1001,15 +1003,16 @@ int cg_phase_persist(mag_ctx *ctx)
         HIPCHK(ctx->grec.reserve(2 * 64));
         HIPCHK(hipMemsetAsync(ctx->grec.p, 0, 2 * 64, s));
         // The window is never zeroed: tags carry the solve's sequence number (same on every rank: all ranks run the
-        // same solves), so nothing of an earlier solve can look current.  4096 solves share 12 bits.
-        ctx->solve_seq = (ctx->solve_seq + 1) & 0xfffu;
+        // same solves) above 24 bits of iteration count, so nothing of an earlier solve can look current (every solve
+        // overwrites the slots of the one before; 255 sequence numbers go round).
+        ctx->solve_seq = (ctx->solve_seq + 1) & 0xffu;
         if (ctx->solve_seq == 0) ctx->solve_seq = 1;
         P.t0 = ctx->t0;
         P.t1 = ctx->t1;
         P.rank = ctx->comm.rank;
         P.nranks = R;
         P.n_iface = ctx->n_iface;
-        P.tag_base = ctx->solve_seq << 20;
+        P.tag_base = ctx->solve_seq << 24;
         P.own_qslot = ctx->own_qslot.as<int32_t>();
         P.halo_qslot = ctx->halo_qslot.as<int32_t>();
         P.win_shared = ctx->inbox_ready ? 0 : 1;

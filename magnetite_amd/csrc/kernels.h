@@ -295,7 +295,7 @@ struct PersistParams {
     // window of host memory every rank has mapped (granules again, system scope): one record of sums per rank, q of the
     // interface nodes.  Tags carry a per-solve sequence number in their upper bits, so the window is never zeroed.
     int32_t t0, t1, rank, nranks, n_iface;
-    uint32_t tag_base;          // solve sequence << 20
+    uint32_t tag_base;          // solve sequence << 24
     const int32_t *own_qslot;   // N: interface slot of an owned node other ranks read, -1 otherwise
     const int32_t *halo_qslot;  // halo_total: interface slot of a halo entry another rank owns, -1 otherwise
     // The window, seen as one INBOX per rank (layout of each: 64 bytes {timeout word}, 2 * nranks * 8 record granules,
