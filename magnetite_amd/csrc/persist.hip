@@ -351,6 +351,46 @@ __device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsi
     return fetch_window_halo() ? true : fail();
 }
 
+// Ring walk without per-entry tests.  k_ring16 pads every row to the tile's row length with entries that repeat the
+// last neighbour and carry the break bit, so every entry below 2 * nwords is a real LDS slot: the walk is a chain of
+// unconditional gathers, the loop bound is a scalar (tile-uniform) branch, and only the ADDITION of a triangle's force
+// is selected by the break bit (a repeated entry spans no area: its force is NaN/inf and is selected out, never
+// multiplied in).  With two waves per SIMD the exec-mask bookkeeping of the branchy walk is pure issue-slot cost.
+template <int NW>
+__device__ inline void ring_walk_uniform(const uint32_t (&w)[NW], const uint32_t *more, int32_t stride, int32_t nwords,
+                                         const double2 *s_xy, const double2 *s_p, const double2 ca, const double2 pa,
+                                         double c0, double nu, double h, double &fx, double &fy)
+{
+    double2 pd, pu;
+    auto step = [&](uint32_t e, bool seed) {
+        const uint32_t id = e & 0xfffu;
+        const double2 cxy = s_xy[id], cp = s_p[id];
+        const double2 d = make_double2(cxy.x - ca.x, cxy.y - ca.y), u = make_double2(cp.x - pa.x, cp.y - pa.y);
+        if (!seed) {
+            double dfx = 0.0, dfy = 0.0;
+            fan_force<double2, double>(pd, pu, d, u, c0, nu, h, dfx, dfy);
+            const bool closes = !(e & 0x8000u);
+            fx += closes ? dfx : 0.0;
+            fy += closes ? dfy : 0.0;
+        }
+        pd = d;
+        pu = u;
+    };
+    step(w[0] & 0xffffu, true);
+    step(w[0] >> 16, false);
+#pragma unroll
+    for (int k = 1; k < NW; ++k)
+        if (k < nwords) {
+            step(w[k] & 0xffffu, false);
+            step(w[k] >> 16, false);
+        }
+    for (int32_t k = NW; k < nwords; ++k) {
+        const uint32_t ww = more[(int64_t)k * stride];
+        step(ww & 0xffffu, false);
+        step(ww >> 16, false);
+    }
+}
+
 // Workgroup totals of four partial sums for the two publishing threads (0 and 1): DPP wave trees, then the eight
 // waves in order.
 __device__ inline void persist_block_sum(double (&acc)[4], double *s_red)
@@ -553,14 +593,10 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
             const double2 ca = xy[lt], pa = pim[lt];
             double fx = 0.0, fy = 0.0;
             {
-                double2 rd = ca, ru = pa;
-                auto tri = [&](const double2 db, const double2 ub, const double2 dc, const double2 uc) {
-                    fan_force<double2, double>(db, ub, dc, uc, c0, nu, h, fx, fy);
-                };
-#pragma unroll
-                for (int k = 0; k < kPersistRegs; ++k) ring_word(w[s][k], xy, pim, ca, pa, rd, ru, tri);
-                for (int32_t k = kPersistRegs; k < deg[s]; ++k)
-                    ring_word(P.ell16[ell_off[s] + (int64_t)k * B], xy, pim, ca, pa, rd, ru, tri);
+                const int32_t nwords = __builtin_amdgcn_readfirstlane(deg[s]); // one tile per wave: a scalar
+                if (nwords > 0)
+                    ring_walk_uniform<kPersistRegs>(w[s], P.ell16 + ell_off[s], B, nwords, xy, pim, ca, pa, c0, nu, h, fx,
+                                                    fy);
             }
             if ((flags[s] & 1) || !(flags[s] & 16)) fx = 0.0;
             if ((flags[s] & 2) || !(flags[s] & 16)) fy = 0.0;

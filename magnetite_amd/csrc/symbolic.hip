@@ -383,6 +383,8 @@ __global__ void __launch_bounds__(256) k_ring16(const int32_t *tile_deg, const i
         int words = 0;
         if (d > kRingMaxDeg) {
             for (int k = 0; k < d; ++k) row[(int64_t)k * B] |= 0x8000u;
+            const uint32_t pad = ((row[(int64_t)(d - 1) * B] >> 16) & 0xfffu) | 0x8000u;
+            for (int k = d; k < td; ++k) row[(int64_t)k * B] = pad | (pad << 16);
             words = d;
         } else if (d > 0) {
             uint32_t pr[kRingMaxDeg];
@@ -426,11 +428,15 @@ __global__ void __launch_bounds__(256) k_ring16(const int32_t *tile_deg, const i
                 }
             }
             words = (n + 1) / 2;
-            for (int k = 0; k < words; ++k) {
-                const uint32_t lo = out[2 * k], hi = 2 * k + 1 < n ? out[2 * k + 1] : 0xffffu;
+            // Padding repeats the last neighbour with the break bit: a walker may treat EVERY entry of the tile's
+            // row length as present (no per-entry test), the repeated entry closes no triangle.
+            const uint32_t pad = (uint32_t)(out[n - 1] & 0xfffu) | 0x8000u;
+            for (int k = 0; k < td; ++k) {
+                const uint32_t lo = 2 * k < n ? out[2 * k] : pad, hi = 2 * k + 1 < n ? out[2 * k + 1] : pad;
                 row[(int64_t)k * B] = lo | (hi << 16);
             }
-            for (int k = words; k < d; ++k) row[(int64_t)k * B] = 0xffffffffu;
+        } else {
+            for (int k = 0; k < td; ++k) row[(int64_t)k * B] = 0x80008000u; // no triangles: slot 0, break, throughout
         }
         wmax = words > wmax ? words : wmax;
     }
