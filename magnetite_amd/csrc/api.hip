@@ -398,11 +398,12 @@ int ensure_order(mag_ctx *ctx)
         magk::fill_ell16(ctx->inc_off.as<int32_t>(), ctx->inc.as<uint32_t>(), ctx->conn.as<int32_t>(),
                          ctx->iperm.as<int32_t>(), ctx->tile_deg.as<int32_t>(), ctx->tile_off.as<int64_t>(),
                          ctx->tile_hoff.as<int32_t>(), ctx->halo_g.as<int32_t>(), N, B, T, ctx->ell.as<uint32_t>(), s);
-        HIPCHK(ctx->tile_rdeg.reserve(4 * ((size_t)T + 1)));
+        HIPCHK(ctx->tile_rdeg.reserve(2 * 4 * ((size_t)T + 1)));
         magk::ring16(ctx->tile_deg.as<int32_t>(), ctx->tile_off.as<int64_t>(), B, T, ctx->ell.as<uint32_t>(),
                      ctx->tile_rdeg.as<int32_t>(), s);
         HIPCHK(ctx->tmeta.reserve(sizeof(magk::TileMeta) * (size_t)T));
-        magk::tile_meta(ctx->tile_rdeg.as<int32_t>(), ctx->tile_off.as<int64_t>(), ctx->tile_hoff.as<int32_t>(), T,
+        magk::tile_meta(ctx->tile_rdeg.as<int32_t>(), ctx->tile_rdeg.as<int32_t>() + T, ctx->tile_off.as<int64_t>(),
+                        ctx->tile_hoff.as<int32_t>(), T,
                         ctx->tmeta.as<magk::TileMeta>(), s);
         magk::mark_published(ctx->halo_g.as<int32_t>(), ctx->halo_total, ctx->maskP.as<uint8_t>(), s);
     } else {

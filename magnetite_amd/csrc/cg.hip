@@ -1402,8 +1402,9 @@ void fused_launch(const FusedParams &P, int32_t B, int32_t grid, hipStream_t s)
     fused_pick(B, dma, P.wt != 0, comm, pre)<<<grid, threads, lds, s>>>(P);
 }
 
-__global__ void __launch_bounds__(256) k_tile_meta(const int32_t *tile_deg, const int64_t *tile_off,
-                                                   const int32_t *tile_hoff, int32_t T, TileMeta *meta)
+__global__ void __launch_bounds__(256) k_tile_meta(const int32_t *tile_deg, const int32_t *tile_ent,
+                                                   const int64_t *tile_off, const int32_t *tile_hoff, int32_t T,
+                                                   TileMeta *meta)
 {
     const int32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= T) return;
@@ -1412,15 +1413,15 @@ __global__ void __launch_bounds__(256) k_tile_meta(const int32_t *tile_deg, cons
     m.deg = tile_deg[t];
     m.hoff = tile_hoff[t];
     m.nh = tile_hoff[t + 1] - tile_hoff[t];
-    m.pad = 0;
+    m.ent = tile_ent[t];
     m.pad2 = 0;
     meta[t] = m;
 }
 
-void tile_meta(const int32_t *tile_deg, const int64_t *tile_off, const int32_t *tile_hoff, int32_t T, TileMeta *meta,
-               hipStream_t s)
+void tile_meta(const int32_t *tile_deg, const int32_t *tile_ent, const int64_t *tile_off, const int32_t *tile_hoff,
+               int32_t T, TileMeta *meta, hipStream_t s)
 {
-    k_tile_meta<<<(T + 255) / 256, 256, 0, s>>>(tile_deg, tile_off, tile_hoff, T, meta);
+    k_tile_meta<<<(T + 255) / 256, 256, 0, s>>>(tile_deg, tile_ent, tile_off, tile_hoff, T, meta);
 }
 
 template <int B>

@@ -206,7 +206,7 @@ struct Rqp {
 };
 struct TileMeta { // one 32-byte scalar load per tile instead of four dependent ones
     int64_t ell_off;
-    int32_t deg, hoff, nh, pad;
+    int32_t deg, hoff, nh, ent; // deg: ring words of the longest row, ent: its entries (2 deg - 1 or 2 deg)
     int64_t pad2;
 };
 struct FusedState {
@@ -249,8 +249,8 @@ struct FusedParams {
 // rewrites the tile-local table of fill_ell16 into ring form in place (symbolic.hip, k_ring16)
 void ring16(const int32_t *tile_deg, const int64_t *tile_off, int32_t B, int32_t T, uint32_t *ell, int32_t *tile_rdeg,
             hipStream_t s);
-void tile_meta(const int32_t *tile_deg, const int64_t *tile_off, const int32_t *tile_hoff, int32_t T, TileMeta *meta,
-               hipStream_t s);
+void tile_meta(const int32_t *tile_deg, const int32_t *tile_ent, const int64_t *tile_off, const int32_t *tile_hoff,
+               int32_t T, TileMeta *meta, hipStream_t s);
 // workgroups of the fused kernel: all co-resident (occupancy query x CUs), so the launch is one persistent round --
 // measured best on MI355X (fewer, fatter workgroups also mean fewer dot partials for every workgroup to reduce)
 int fused_grid(int32_t B, int32_t cap, int32_t tiles, bool comm, bool pre);

@@ -357,7 +357,7 @@ __device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsi
 // is selected by the break bit (a repeated entry spans no area: its force is NaN/inf and is selected out, never
 // multiplied in).  With two waves per SIMD the exec-mask bookkeeping of the branchy walk is pure issue-slot cost.
 template <int NW>
-__device__ inline void ring_walk_uniform(const uint32_t (&w)[NW], const uint32_t *more, int32_t stride, int32_t nwords,
+__device__ inline void ring_walk_uniform(const uint32_t (&w)[NW], const uint32_t *more, int32_t stride, int32_t nent,
                                          const double2 *s_xy, const double2 *s_p, const double2 ca, const double2 pa,
                                          double c0, double nu, double h, double &fx, double &fy)
 {
@@ -377,17 +377,12 @@ __device__ inline void ring_walk_uniform(const uint32_t (&w)[NW], const uint32_t
         pu = u;
     };
     step(w[0] & 0xffffu, true);
-    step(w[0] >> 16, false);
 #pragma unroll
-    for (int k = 1; k < NW; ++k)
-        if (k < nwords) {
-            step(w[k] & 0xffffu, false);
-            step(w[k] >> 16, false);
-        }
-    for (int32_t k = NW; k < nwords; ++k) {
-        const uint32_t ww = more[(int64_t)k * stride];
-        step(ww & 0xffffu, false);
-        step(ww >> 16, false);
+    for (int k = 1; k < 2 * NW; ++k)
+        if (k < nent) step((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu), false); // nent: a scalar
+    for (int32_t k = 2 * NW; k < nent; ++k) {
+        const uint32_t ww = more[(int64_t)(k >> 1) * stride];
+        step((k & 1) ? (ww >> 16) : (ww & 0xffffu), false);
     }
 }
 
@@ -436,7 +431,7 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
 
     constexpr int NH = kPersistNh; // halo entries per thread: the workgroup's halo nodes are dealt out over ALL threads
     const unsigned tag0 = (MG ? P.tag_base : 0u) + 1u; // tag of epoch e: tag0 + e - 1
-    int32_t node[NPT], deg[NPT], oslot[NPT];
+    int32_t node[NPT], deg[NPT], ent[NPT], oslot[NPT];
     int32_t hg[NH], hloc[NH]; // global id (-1: none) and LDS position (tile * tile_words-relative) of a halo entry
     uint32_t flags[NPT]; // bit 0/1 prescribed ux/uy, 2 published, 3 live tile, 4 valid node
     uint32_t w[NPT][kPersistRegs];
@@ -452,6 +447,7 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
         node[s] = 0;
         oslot[s] = -1;
         deg[s] = 0;
+        ent[s] = 0;
         flags[s] = 3;
         ell_off[s] = 0;
         r[s] = q[s] = make_double2(0.0, 0.0);
@@ -475,6 +471,7 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
         pim[lt] = make_double2(0.0, 0.0);
         xs[lt] = make_double2(0.0, 0.0);
         deg[s] = tm.deg;
+        ent[s] = tm.ent;
         ell_off[s] = tm.ell_off + lt;
 #pragma unroll
         for (int k = 0; k < kPersistRegs; ++k)
@@ -593,9 +590,9 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
             const double2 ca = xy[lt], pa = pim[lt];
             double fx = 0.0, fy = 0.0;
             {
-                const int32_t nwords = __builtin_amdgcn_readfirstlane(deg[s]); // one tile per wave: a scalar
-                if (nwords > 0)
-                    ring_walk_uniform<kPersistRegs>(w[s], P.ell16 + ell_off[s], B, nwords, xy, pim, ca, pa, c0, nu, h, fx,
+                const int32_t nent = __builtin_amdgcn_readfirstlane(ent[s]); // one tile per wave: a scalar
+                if (nent > 0)
+                    ring_walk_uniform<kPersistRegs>(w[s], P.ell16 + ell_off[s], B, nent, xy, pim, ca, pa, c0, nu, h, fx,
                                                     fy);
             }
             if ((flags[s] & 1) || !(flags[s] & 16)) fx = 0.0;

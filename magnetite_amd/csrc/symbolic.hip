@@ -375,7 +375,7 @@ __global__ void __launch_bounds__(256) k_ring16(const int32_t *tile_deg, const i
     const int32_t t = blockIdx.x;
     const int32_t td = tile_deg[t];
     uint32_t *dst = ell + tile_off[t];
-    int32_t wmax = 0;
+    int32_t wmax = 0, emax = 0;
     for (int l = threadIdx.x; l < B; l += 256) {
         uint32_t *row = dst + l; // row[k * B], k < td
         int d = 0;
@@ -386,6 +386,7 @@ __global__ void __launch_bounds__(256) k_ring16(const int32_t *tile_deg, const i
             const uint32_t pad = ((row[(int64_t)(d - 1) * B] >> 16) & 0xfffu) | 0x8000u;
             for (int k = d; k < td; ++k) row[(int64_t)k * B] = pad | (pad << 16);
             words = d;
+            emax = 2 * d > emax ? 2 * d : emax;
         } else if (d > 0) {
             uint32_t pr[kRingMaxDeg];
             uint16_t out[2 * kRingMaxDeg];
@@ -428,6 +429,7 @@ __global__ void __launch_bounds__(256) k_ring16(const int32_t *tile_deg, const i
                 }
             }
             words = (n + 1) / 2;
+            emax = n > emax ? n : emax;
             // Padding repeats the last neighbour with the break bit: a walker may treat EVERY entry of the tile's
             // row length as present (no per-entry test), the repeated entry closes no triangle.
             const uint32_t pad = (uint32_t)(out[n - 1] & 0xfffu) | 0x8000u;
@@ -441,12 +443,13 @@ __global__ void __launch_bounds__(256) k_ring16(const int32_t *tile_deg, const i
         wmax = words > wmax ? words : wmax;
     }
     if (wmax > 0) atomicMax(&tile_rdeg[t], wmax);
+    if (emax > 0) atomicMax(&tile_rdeg[gridDim.x + t], emax); // second half of the array: entries of the longest row
 }
 
 void ring16(const int32_t *tile_deg, const int64_t *tile_off, int32_t B, int32_t T, uint32_t *ell, int32_t *tile_rdeg,
             hipStream_t s)
 {
-    (void)hipMemsetAsync(tile_rdeg, 0, 4 * (size_t)T, s);
+    (void)hipMemsetAsync(tile_rdeg, 0, 2 * 4 * (size_t)T, s); // [0, T): words, [T, 2T): entries of the longest row
     k_ring16<<<T, 256, 0, s>>>(tile_deg, tile_off, B, ell, tile_rdeg);
 }
 
