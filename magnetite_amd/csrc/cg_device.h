@@ -87,4 +87,39 @@ __device__ inline void fan_force(const V2 db, const V2 ub, const V2 dc, const V2
     fy += w * (ga * sy + ba * tq);
 }
 
+// Ring walk without per-entry tests.  k_ring16 pads every row to the tile's row length with entries that repeat the
+// last neighbour and carry the break bit, so every entry below 2 * nwords is a real LDS slot: the walk is a chain of
+// unconditional gathers, the loop bound is a scalar (tile-uniform) branch, and only the ADDITION of a triangle's force
+// is selected by the break bit (a repeated entry spans no area: its force is NaN/inf and is selected out, never
+// multiplied in).  With two waves per SIMD the exec-mask bookkeeping of the branchy walk is pure issue-slot cost.
+template <int NW>
+__device__ inline void ring_walk_uniform(const uint32_t (&w)[NW], const uint32_t *more, int32_t stride, int32_t nent,
+                                         const double2 *s_xy, const double2 *s_p, const double2 ca, const double2 pa,
+                                         double c0, double nu, double h, double &fx, double &fy)
+{
+    double2 pd, pu;
+    auto step = [&](uint32_t e, bool seed) {
+        const uint32_t id = e & 0xfffu;
+        const double2 cxy = s_xy[id], cp = s_p[id];
+        const double2 d = make_double2(cxy.x - ca.x, cxy.y - ca.y), u = make_double2(cp.x - pa.x, cp.y - pa.y);
+        if (!seed) {
+            double dfx = 0.0, dfy = 0.0;
+            fan_force<double2, double>(pd, pu, d, u, c0, nu, h, dfx, dfy);
+            const bool closes = !(e & 0x8000u);
+            fx += closes ? dfx : 0.0;
+            fy += closes ? dfy : 0.0;
+        }
+        pd = d;
+        pu = u;
+    };
+    step(w[0] & 0xffffu, true);
+#pragma unroll
+    for (int k = 1; k < 2 * NW; ++k)
+        if (k < nent) step((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu), false); // nent: a scalar
+    for (int32_t k = 2 * NW; k < nent; ++k) {
+        const uint32_t ww = more[(int64_t)(k >> 1) * stride];
+        step((k & 1) ? (ww >> 16) : (ww & 0xffffu), false);
+    }
+}
+
 } // namespace magk
