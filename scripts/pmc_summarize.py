@@ -47,7 +47,10 @@ if len(pk) >= 2:
     b0, b1 = hbm(acc[(k0, i0)]), hbm(acc[(k1, i1)])
     per_it = (b1 - b0) / (i1 - i0)
     summary["hole1m:tile512:kernel2"] = {"kernel": k0, "runs": {str(i0): b0, str(i1): b1},
-                                         "hbm_bytes_per_iteration": per_it, "hbm_bytes_setup": b0 - per_it * i0,
+                                         "hbm_bytes_per_iteration": per_it,
+                                         # two single-launch samples: the intercept is noisy (the sweeps of a run
+                                         # repeat a data-dependent number of times); never below zero
+                                         "hbm_bytes_setup": max(0.0, b0 - per_it * i0),
                                          "note": note + "; one launch per solve, two run lengths"}
 json.dump(summary, open(os.path.join(root, "profiles", "r01_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
