@@ -803,3 +803,32 @@ def test_on_chip_cg_falls_back_when_the_grid_barrier_times_out(built, monkeypatc
     with Context(device=0, tile_nodes=512) as c:
         c.solve(p)
         assert c.stats()["cg_kernel"] == 2
+
+
+def test_on_chip_cg_with_rings_longer_than_its_registers(built):
+    """A node of valence 40 (its row becomes 80 single-triangle entries) and one of valence 12 in 512-node tiles: the
+    on-chip kernel keeps ten ring entries per node in registers and walks the rest of the tile's longest row from
+    the table in memory."""
+    n = 40
+    ang = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    xy = np.concatenate([[[0.0, 0.0]], np.stack([np.cos(ang), np.sin(ang)], axis=1),
+                         1.8 * np.stack([np.cos(ang), np.sin(ang)], axis=1)])
+    tri = [[0, 1 + k, 1 + (k + 1) % n] for k in range(n)]
+    tri += [[1 + k, 1 + n + k, 1 + n + (k + 1) % n] for k in range(n)]
+    tri += [[1 + k, 1 + n + (k + 1) % n, 1 + (k + 1) % n] for k in range(n)]
+    rules = [meshgen.BoundaryRule("hold", x_max=-1.2, ux=0.0, uy=0.0), meshgen.BoundaryRule("pull", x_min=1.2, ux=0.01, fy=0.0)]
+    p40 = meshgen.apply_boundary_rules(meshgen.Mesh(xy, np.array(tri, dtype=np.int32), "fan40"), rules)
+    m12 = 12
+    ang = np.linspace(0, 2 * np.pi, m12, endpoint=False)
+    xy = np.concatenate([[[0.0, 0.0]], np.stack([np.cos(ang), np.sin(ang)], axis=1),
+                         1.8 * np.stack([np.cos(ang), np.sin(ang)], axis=1)])
+    tri = [[0, 1 + k, 1 + (k + 1) % m12] for k in range(m12)]
+    tri += [[1 + k, 1 + m12 + k, 1 + m12 + (k + 1) % m12] for k in range(m12)]
+    tri += [[1 + k, 1 + m12 + (k + 1) % m12, 1 + (k + 1) % m12] for k in range(m12)]
+    p12 = meshgen.apply_boundary_rules(meshgen.Mesh(xy, np.array(tri, dtype=np.int32), "fan12"), rules)
+    for p in (p40, p12):
+        ref = oracle_run(p)
+        with Context(device=0, tile_nodes=512) as c:
+            out = c.solve(p)
+            assert c.stats()["cg_kernel"] == 2
+        assert rel(out["u"], ref["u"]) <= TOL_U and abs(out["iterations"] - ref["iterations"]) <= 3
