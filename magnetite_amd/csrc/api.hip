@@ -1052,7 +1052,7 @@ int cg_phase_persist(mag_ctx *ctx)
     P.hist = ctx->hist.as<double>();
     if (mg) {
         // every rank's kernel must be running before anybody's spin budget runs out: line the streams up first
-        P.spin_limit = 1u << 21;
+        if (!getenv("MAG_TUNE_PERSIST_SPIN")) P.spin_limit = 1u << 21; // ranks start apart: a longer budget
         std::string msg;
         HIPCHK(hipMemsetAsync(ctx->comm_pq.p, 0, 8, s));
         if (int rc = ctx->comm.allreduce_sum(ctx->comm_pq.as<double>(), 1, s, msg)) return fail(ctx, rc, "%s", msg.c_str());

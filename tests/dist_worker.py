@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--window", type=int, default=0,
                     help="on-chip CG on every rank: 1 = exchange through a shared host-memory window, 2 = through "
                          "per-rank inboxes in device memory (HIP IPC)")
+    ap.add_argument("--expect-kernel", type=int, default=2, help="with --window: mag_stats.cg_kernel every rank must report")
     ap.add_argument("--stacked", type=int, default=0, help="bench.py's weak-scaling geometry: plate-with-hole stacked N times")
     a = ap.parse_args()
     import torch
@@ -90,7 +91,7 @@ def main():
                     c.close_inboxes()
         if a.window:
             print(f"rank {rank}: cg_kernel {kernel}", flush=True)
-            assert kernel == 2, kernel
+            assert kernel == a.expect_kernel, kernel
             dist.barrier()
             if shm is not None:
                 shm.close()

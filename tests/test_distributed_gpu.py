@@ -31,7 +31,16 @@ def test_four_ranks_on_the_weak_scaling_geometry(built):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
 
 
-@pytest.mark.parametrize("nproc", [2, 3])
+def test_on_chip_cg_across_ranks_falls_back_together(built):
+    """MAG_TUNE_PERSIST_SPIN=0: every wait of the multi-GPU on-chip kernel gives up at once.  The ranks must agree on
+    it (one all-reduce of the failure flags), redo the solve with the streaming kernels + one all-reduce per iteration
+    and still return the right answer, identically, on every rank."""
+    r = launch(3, "callback", 29597, 1, ("--window", "2", "--tile", "512", "--mesh", "120", "--expect-kernel", "1"),
+               {"MAG_TUNE_PERSIST_MIN_K": "1", "MAG_TUNE_PERSIST_SPIN": "0"})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("nproc", [2, 3, 4])
 def test_on_chip_cg_across_ranks_through_device_inboxes(built, nproc):
     """The same protocol with one inbox per rank in DEVICE memory, mapped by the other ranks through HIP IPC: a rank
     polls only its own inbox, writers store into the inboxes of the ranks that read a value.  (Here the ranks share
