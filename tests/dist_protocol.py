@@ -10,7 +10,12 @@ all-reduce.  Checks the result against the single-process oracle CG.
 all-reduce per iteration on a parity-double-buffered exchange buffer
     [r.r | p.q | r.q | q.q partials, G slots each, summed slot by slot | q on interface nodes (owner's value, 0 elsewhere)]
 launch j reads the all-reduced buffer [j & 1] (sums and ghost q of iterate j-1), advances owned and ghost records,
-and fills buffer [(j & 1) ^ 1]; beta's numerator is expanded from the exact sums of the previous iterate."""
+and fills buffer [(j & 1) ^ 1]; beta's numerator is expanded from the exact sums of the previous iterate.
+
+`--onchip` restates the multi-GPU on-chip CG (persist.hip, k_cg_persist<.., MG>): no collective per iteration -- every
+rank keeps r, p of its halo nodes itself, the owner of an interface node delivers its q into the INBOX of exactly the
+ranks that read it, every rank delivers its four sums into every rank's inbox and adds the R records in rank order
+(inboxes are modelled by an all-gather of what each rank would store)."""
 import os
 import sys
 
@@ -66,6 +71,18 @@ def main():
         dist.all_reduce(t)
         return v
 
+    if "--onchip" in sys.argv:
+        readers = {}                                   # interface DOF -> ranks that read it (rows of theirs touch it)
+        for s_ in range(world):
+            rows = np.where(dof_owner == s_)[0]
+            cols = np.unique(A[rows].indices)
+            for c in cols:
+                if dof_owner[c] != s_:
+                    readers.setdefault(int(c), set()).add(s_)
+        it, x = onchip_protocol(K.n, b, Arows, mine, dof_owner, readers, rank, world)
+        finish(p, free, x, mine, it, iface, rank, world, allreduce)
+        return
+
     if "--fused" in sys.argv:
         it, x = fused_protocol(K.n, b, Arows, mine, iface_dofs, iface_mine, rank, allreduce)
         finish(p, free, x, mine, it, iface, rank, world, allreduce)
@@ -114,6 +131,58 @@ def finish(p, free, x, mine, it, iface, rank, world, allreduce):
     ok = err <= 1e-8 and abs(it - ref["iterations"]) <= max(3, ref["iterations"] // 50) and iface.size > 0
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)
+
+
+def onchip_protocol(n, b, Arows, mine, dof_owner, readers, rank, world, target=1e-4):
+    """One rank of the multi-GPU on-chip CG.  State: r, q, p, x of owned DOFs; r, p of the halo DOFs it reads."""
+    import torch.distributed as dist
+
+    halo = np.array(sorted(c for c, rs in readers.items() if rank in rs), dtype=np.int64)  # what this rank reads
+    keep = mine.copy()
+    keep[halo] = True                              # DOFs this rank carries at all
+    r, q, pp, x = np.where(keep, -b, 0.0), np.zeros(n), np.zeros(n), np.zeros(n)
+
+    def exchange(record, qvals):
+        """Inboxes: every rank ends up with all R records and with the q of the halo DOFs it reads."""
+        deliveries = {}
+        for c, rs in readers.items():
+            if dof_owner[c] == rank:
+                for dst in rs:                     # the owner stores into each reader's inbox, nobody else's
+                    deliveries.setdefault(dst, {})[c] = qvals[c]
+        box = [None] * world
+        dist.all_gather_object(box, (record, deliveries))
+        total = np.zeros(4)
+        for s_ in range(world):                    # rank order: the same bits on every rank
+            total = total + box[s_][0]
+        got = {}
+        for s_ in range(world):
+            got.update(box[s_][1].get(rank, {}))
+        assert set(got) == set(halo.tolist())
+        return total, got
+
+    rec = np.array([np.dot(b[mine], b[mine]), 1.0 if rank == 0 else 0.0, 0.0, 0.0])
+    S, got = exchange(rec, q)
+    j = 0
+    while j < 200000:
+        rr = S[0]
+        it_done = j - 1
+        if it_done >= 1 and np.sqrt(rr) <= target:
+            return it_done, x
+        alpha = rr / S[1]
+        beta = (rr + 2.0 * alpha * S[2] + alpha * alpha * S[3]) / rr
+        for c, v in got.items():
+            q[c] = v                               # q_{j-1} of the halo from the inbox
+        x[mine] += alpha * pp[mine]
+        r[keep] += alpha * q[keep]
+        pn = np.zeros(n)
+        pn[keep] = -r[keep] + beta * pp[keep]      # owned and halo alike, by the same recurrences
+        qn = Arows @ pn
+        q[mine] = qn
+        pp = pn
+        rec = np.array([np.dot(r[mine], r[mine]), np.dot(pn[mine], qn), np.dot(r[mine], qn), np.dot(qn, qn)])
+        S, got = exchange(rec, q)
+        j += 1
+    return j, x
 
 
 def fused_protocol(n, b, Arows, mine, iface_dofs, iface_mine, rank, allreduce, target=1e-4, G=4):
