@@ -832,3 +832,20 @@ def test_on_chip_cg_with_rings_longer_than_its_registers(built):
             out = c.solve(p)
             assert c.stats()["cg_kernel"] == 2
         assert rel(out["u"], ref["u"]) <= TOL_U and abs(out["iterations"] - ref["iterations"]) <= 3
+
+
+def test_one_context_alternates_between_streaming_and_on_chip_solves(built):
+    """The same context solves a mesh the library streams (auto tile 256), one it keeps on chip (auto tile 512), and the
+    first again: tile size, tables, graph and kernel choice all follow the problem, results equal fresh contexts'."""
+    small = meshgen.config_fixed_left_pull_right(meshgen.plate_with_holes(150))      # 22k nodes: streamed
+    mid = meshgen.config_fixed_left_pull_right(meshgen.plate_with_holes(300))        # 90k nodes: on chip
+    fresh = {}
+    for name, p in (("small", small), ("mid", mid)):
+        with Context(device=0) as c:
+            fresh[name] = (c.solve(p), c.stats()["cg_kernel"])
+    assert fresh["small"][1] == 1 and fresh["mid"][1] == 2
+    with Context(device=0) as c:
+        for name, p in (("small", small), ("mid", mid), ("small", small), ("mid", mid)):
+            out = c.solve(p)
+            assert c.stats()["cg_kernel"] == fresh[name][1]
+            assert np.array_equal(out["u"], fresh[name][0]["u"]) and out["iterations"] == fresh[name][0]["iterations"]
