@@ -11,22 +11,23 @@
 namespace magk {
 
 // ============================================ on-chip (persistent) CG ===
-// When the whole mesh fits the chip -- every workgroup keeps 2 * (1024 / B) tiles: r, q, p, x of their nodes in
-// registers, coordinates and the p image in LDS, the ring words in registers -- the CG state never moves through
-// HBM again: ONE launch runs the whole solve.  Per iteration a workgroup only publishes q of the nodes other tiles
-// read and its four dot partials, as tagged granules (below); every workgroup then sweeps every workgroup's record
-// and the q of its own halo nodes until all tags carry the iteration's epoch -- that sweep IS the grid barrier -- and
-// sums the records in one fixed order: the same bits in every workgroup, so all of them take the same stop decision
-// in the same iteration.  Spins are bounded (a workgroup that gives up sets the timeout word and leaves; the host
-// then falls back to the streaming kernels).  Same recurrences and state machine as
-// k_cg_fused (alpha, beta from the four exact sums of the previous iterate).
+// When the whole mesh fits the chip -- one workgroup of 512 threads per CU keeps up to four 512-node tiles: r, q and
+// the ring words of its nodes in registers; coordinates, the p image (its owned part is the CG vector p), x and the
+// halo copies of r, p in LDS -- the CG state never moves through HBM again: ONE launch runs the whole solve.  Per
+// iteration a workgroup only publishes q of the nodes other tiles read and its four dot partials, as tagged granules
+// (below); every workgroup then sweeps every workgroup's record and the q of its own halo nodes until all tags carry
+// the iteration's epoch -- that sweep IS the grid barrier -- and sums the records in one fixed order: the same bits
+// in every workgroup, so all of them take the same stop decision in the same iteration.  Spins are bounded (a
+// workgroup that gives up sets the timeout word and leaves; the host then falls back to the streaming kernels).
+// Same recurrences and state machine as k_cg_fused (alpha, beta from the four exact sums of the previous iterate).
+// MG instantiation: several GPUs, each running its tile range, exchanging through per-rank inboxes (further down).
 typedef __attribute__((address_space(1))) unsigned int gu32;
 constexpr int kPersistThreads = 512; // 8 waves per CU = 2 per SIMD: 256 VGPRs per lane, no spills with 4 nodes per thread
 
 // Inter-workgroup exchange by self-validating granules (CDNA4 guide, Guideline 16 R2: "the data IS the flag"): every
-// handed-off 32-bit half travels in its own naturally aligned 8-byte word {tag = epoch, value}, written by ONE relaxed
-// agent-scope atomic store and read by relaxed agent-scope atomic loads until the tag matches.  No arrival counters,
-// no store drains, no fences: a reader can never take a stale or torn value for the current one.  Two buffers by
+// handed-off 32-bit half travels in its own naturally aligned 8-byte word {value, tag = epoch}; two of them are written
+// by one 16-byte write-through store and read by one 16-byte sc1 load, again and again until every tag matches.  No
+// arrival counters, no store drains, no fences: a reader can never take a stale or torn value for the current one.  Two buffers by
 // parity: nobody can be two epochs ahead of a workgroup that has not finished reading (it would need that workgroup's
 // next record first).
 typedef __attribute__((address_space(1))) unsigned long long gu64;
@@ -44,8 +45,8 @@ __device__ inline void put_granules(unsigned long long *g, unsigned epoch, doubl
                  : "memory");
 }
 
-// Four granules (32 bytes) by two 16-byte sc1 loads: each 8-byte granule was written by one atomic store and validates
-// itself, so it does not matter that the pair is not read atomically.  `base` must be wave-uniform (it becomes the
+// Four granules (32 bytes) by two 16-byte sc1 loads: each 8-byte granule lies whole inside one store and validates
+// itself, so it does not matter that the group is not read atomically.  `base` must be wave-uniform (it becomes the
 // buffer resource), the granule group is addressed by the per-lane byte offset.
 __device__ inline bool get_granules(const unsigned long long *base, uint32_t bytes, uint32_t off, unsigned epoch,
                                     double2 &v)
