@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MAG_ABI_VERSION 1
+#define MAG_ABI_VERSION 2
 
 /* solver.rs:17-19 */
 #define MAG_DOF 2
@@ -50,7 +50,11 @@ enum mag_status {
     MAG_OK = 0,
     MAG_ERR_BAD_ARGS = 1,
     MAG_ERR_BC_MISMATCH = 2,   /* no unknown displacement / inconsistent BC set (solver.rs:431 panics) */
-    MAG_ERR_NOT_CONVERGED = 3, /* CG hit max_iter or broke down (solver.rs:160-174 -> Err)      */
+    MAG_ERR_NOT_CONVERGED = 3, /* CG broke down: non-finite residual.  (The iteration cap is NOT an error: argmin's
+                                  MaxItersReached is a normal termination and solver.rs:149-176 returns Ok(best_param);
+                                  mag_run then returns MAG_OK with stats.converged = 0, stats.termination =
+                                  MAG_TERM_MAX_ITERS and the lowest-cost iterate.  solver.rs:160-166 maps only an
+                                  argmin Err, solver.rs:167-174 a missing best_param, to MagnetiteError::Solver.)   */
     MAG_ERR_HIP = 4,
     MAG_ERR_RCCL = 5,
     MAG_ERR_TOO_LARGE = 6,     /* an index would not fit int32                                   */
@@ -64,6 +68,14 @@ enum mag_stop {
     MAG_STOP_RNORM = 0,    /* sqrt(r.r) <= tol            (reference-compatible default) */
     MAG_STOP_RNORM_SQ = 1, /* r.r       <= tol                                            */
     MAG_STOP_REL = 2       /* sqrt(r.r) <= tol*sqrt(b.b)  (BASELINE config 3: "CG to 1e-8") */
+};
+
+/* Why the CG stopped (argmin's TerminationReason as the reference's Executor can produce it, solver.rs:149-157). */
+enum mag_termination {
+    MAG_TERM_NONE = 0,        /* no solve yet                                                              */
+    MAG_TERM_TARGET_COST = 1, /* best_cost <= target_cost (solver.rs:154)                                  */
+    MAG_TERM_MAX_ITERS = 2,   /* iter >= max_iters (solver.rs:153): the BEST iterate is returned            */
+    MAG_TERM_BREAKDOWN = 3    /* non-finite residual (no reference counterpart: argmin would iterate on NaN) */
 };
 
 enum mag_operator {
@@ -162,6 +174,11 @@ typedef struct mag_stats {
     double ms_cg;        /* solver.rs:435-441 timed region minus the dense->CSR scan */
     double ms_post;      /* scatter-back, reactions, stress */
     double ms_total;
+    int64_t best_iteration; /* the iteration whose iterate is returned: argmin's best_param (solver.rs:167-174).  Equal to
+                               `iterations` unless the solve stopped at the iteration cap                            */
+    int32_t termination;    /* enum mag_termination */
+    int32_t persist_timeout; /* 1: the on-chip CG kernel gave up at its grid barrier in this run (not every workgroup was
+                               co-resident) and the streaming kernels redid the solve; the context streams from then on */
 } mag_stats;
 
 /* ---- lifecycle ------------------------------------------------------- */

@@ -16,6 +16,7 @@ MAG_OK, MAG_ERR_BAD_ARGS, MAG_ERR_BC_MISMATCH, MAG_ERR_NOT_CONVERGED = 0, 1, 2, 
 MAG_ERR_HIP, MAG_ERR_RCCL, MAG_ERR_TOO_LARGE, MAG_ERR_STATE = 4, 5, 6, 7
 MAG_STOP_RNORM, MAG_STOP_RNORM_SQ, MAG_STOP_REL = 0, 1, 2
 MAG_OP_MATRIX_FREE, MAG_OP_CSR = 0, 1
+MAG_TERM_NONE, MAG_TERM_TARGET_COST, MAG_TERM_MAX_ITERS, MAG_TERM_BREAKDOWN = 0, 1, 2, 3
 MAG_MEM_HOST, MAG_MEM_DEVICE = 0, 1
 MAG_UNIQUE_ID_BYTES = 128
 MAG_IPC_HANDLE_BYTES = 64
@@ -57,7 +58,8 @@ class Stats(C.Structure):
                 ("max_tile_halo", C.c_int32), ("lds_operator", C.c_int32), ("cg_kernel", C.c_int32),
                 ("reserved", C.c_int32), ("ms_order", C.c_double),
                 ("ms_csr_symbolic", C.c_double), ("ms_element", C.c_double), ("ms_assemble", C.c_double),
-                ("ms_bc", C.c_double), ("ms_cg", C.c_double), ("ms_post", C.c_double), ("ms_total", C.c_double)]
+                ("ms_bc", C.c_double), ("ms_cg", C.c_double), ("ms_post", C.c_double), ("ms_total", C.c_double),
+                ("best_iteration", C.c_int64), ("termination", C.c_int32), ("persist_timeout", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

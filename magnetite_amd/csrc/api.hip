@@ -124,6 +124,9 @@ struct mag_ctx {
     bool inbox_ready = false;
     DevBuf iface_readers;
     uint32_t solve_seq = 0;
+    double best_cost = 0.0;   // argmin's best_param bookkeeping, as the CG phase that just ran reported it
+    long long best_iter = 0;
+    bool persist_timed_out = false; // the on-chip kernel gave up at its grid barrier in this run (mag_stats.persist_timeout)
     int nsums() const { return pre ? 5 : 4; }
     DevBuf xy32, hxy32, rqp32a, rqp32b, x32; // fp32 leg (mag_options.precision = 1)
     hipGraphExec_t graph = nullptr;
@@ -755,6 +758,8 @@ int cg_phase(mag_ctx *ctx)
     ctx->stats.rhs_norm = std::sqrt(st.bb);
     ctx->stats.converged = st.converged;
     ctx->stats.breakdown = st.breakdown;
+    ctx->best_cost = st.best_cost;
+    ctx->best_iter = st.best_iter;
     return MAG_OK;
 }
 
@@ -972,6 +977,8 @@ int cg_phase_fused(mag_ctx *ctx)
     ctx->stats.rhs_norm = std::sqrt(st.bb);
     ctx->stats.converged = st.converged;
     ctx->stats.breakdown = st.breakdown;
+    ctx->best_cost = st.best_cost;
+    ctx->best_iter = st.best_iter;
     return MAG_OK;
 }
 
@@ -1084,6 +1091,7 @@ int cg_phase_persist(mag_ctx *ctx)
         // a workgroup gave up waiting at the grid barrier (not every workgroup resident: the GPU is shared with
         // another process, or fewer CUs are usable than reported): use the streaming kernels from now on
         ctx->persist_failed = true;
+        ctx->persist_timed_out = true;
         ctx->persist = false;
         if (ctx->opt.verbose) printf("info: on-chip CG not co-resident, falling back to the streaming iteration\n");
         ctx->cg_kernel = 1;
@@ -1102,6 +1110,8 @@ int cg_phase_persist(mag_ctx *ctx)
     ctx->stats.rhs_norm = std::sqrt(st.bb);
     ctx->stats.converged = st.converged;
     ctx->stats.breakdown = st.breakdown;
+    ctx->best_cost = st.best_cost;
+    ctx->best_iter = st.best_iter;
     return MAG_OK;
 }
 
@@ -1208,6 +1218,8 @@ int cg_phase_csr(mag_ctx *ctx)
     ctx->stats.rhs_norm = std::sqrt(st.bb);
     ctx->stats.converged = st.converged;
     ctx->stats.breakdown = st.breakdown;
+    ctx->best_cost = st.best_cost;
+    ctx->best_iter = st.best_iter;
     return MAG_OK;
 }
 
@@ -1287,6 +1299,8 @@ int cg_phase_fused32(mag_ctx *ctx)
     ctx->stats.rhs_norm = std::sqrt(st.bb);
     ctx->stats.converged = st.converged;
     ctx->stats.breakdown = st.breakdown;
+    ctx->best_cost = st.best_cost;
+    ctx->best_iter = st.best_iter;
     return MAG_OK;
 }
 
@@ -1518,11 +1532,34 @@ int mag_run(mag_ctx *ctx)
                     "preconditioner needs the fused LDS iteration: cg_variant 1, precision fp64, matrix-free operator, "
                     "every tile within LDS");
     ctx->cg_kernel = csr_op ? 3 : (f32 ? 4 : (ctx->fused ? 1 : 0));
-    if (int rc = csr_op ? cg_phase_csr(ctx)
-                        : (f32 ? cg_phase_fused32(ctx)
-                               : (ctx->persist ? cg_phase_persist(ctx)
-                                               : (ctx->fused ? cg_phase_fused(ctx) : cg_phase(ctx)))))
-        return rc;
+    ctx->persist_timed_out = false;
+    auto cg_dispatch = [&]() {
+        return csr_op ? cg_phase_csr(ctx)
+                      : (f32 ? cg_phase_fused32(ctx)
+                             : (ctx->persist ? cg_phase_persist(ctx) : (ctx->fused ? cg_phase_fused(ctx) : cg_phase(ctx))));
+    };
+    if (int rc = cg_dispatch()) return rc;
+    st.best_iteration = st.iterations;
+    st.termination = st.breakdown ? MAG_TERM_BREAKDOWN : (st.converged ? MAG_TERM_TARGET_COST : MAG_TERM_MAX_ITERS);
+    if (st.termination == MAG_TERM_MAX_ITERS && ctx->best_iter >= 1 && ctx->best_iter < st.iterations) {
+        // solver.rs:167-174 returns state.best_param: at the iteration cap that is the lowest-cost iterate, not the
+        // last one (plain CG's residual norm is not monotone).  The kernels are bitwise reproducible, so the solve is
+        // simply repeated up to that iteration -- nothing is paid for this on the hot path.
+        const mag_stats first = st;
+        const double best_cost = ctx->best_cost;
+        const long long best_iter = ctx->best_iter;
+        const int64_t cap = ctx->opt.max_iter;
+        ctx->opt.max_iter = best_iter;
+        const int rc = cg_dispatch();
+        ctx->opt.max_iter = cap;
+        if (rc) return rc;
+        st.iterations = first.iterations; // what argmin's observer prints: state.get_iter() (solver.rs:101-104)
+        st.converged = 0;
+        st.breakdown = 0;
+        st.termination = MAG_TERM_MAX_ITERS;
+        st.best_iteration = best_iter;
+        st.final_cost = best_cost;
+    }
     HIPCHK(hipEventRecord(ctx->ev[6], s));
     if (ctx->opt.verbose)
         printf("info: finished conjugate gradient approximation in %lld iterations\n", (long long)st.iterations);
@@ -1565,12 +1602,15 @@ int mag_run(mag_ctx *ctx)
     st.cg_kernel = ctx->cg_kernel;
     st.n_free = ctx->nf;
     ctx->have_run = true;
+    st.persist_timeout = ctx->persist_timed_out ? 1 : 0;
     if (st.breakdown)
         return fail(ctx, MAG_ERR_NOT_CONVERGED, "Conjugate Gradient error: non-finite residual after %lld iterations",
                     (long long)st.iterations);
+    // The iteration cap is a NORMAL termination in the reference (argmin's MaxItersReached; solver.rs:149-176 returns
+    // Ok(best_param)): MAG_OK, stats.converged = 0, stats.termination = MAG_TERM_MAX_ITERS, the best iterate returned.
     if (!st.converged)
-        return fail(ctx, MAG_ERR_NOT_CONVERGED, "Conjugate Gradient did not reach cost %.3e in %lld iterations (cost %.3e)",
-                    ctx->opt.tol, (long long)st.iterations, st.final_cost);
+        ctx->err = "Conjugate Gradient stopped at the iteration cap (" + std::to_string((long long)st.iterations) +
+                   " iterations) above the target cost: best iterate returned (cost " + std::to_string(st.final_cost) + ")";
     return MAG_OK;
 }
 
@@ -1592,7 +1632,7 @@ int mag_solve(mag_ctx *ctx, const mag_problem *p, mag_result *r)
 {
     if (int rc = mag_upload(ctx, p)) return rc;
     const int rc_run = mag_run(ctx);
-    if (rc_run != MAG_OK && rc_run != MAG_ERR_NOT_CONVERGED) return rc_run;
+    if (rc_run != MAG_OK && rc_run != MAG_ERR_NOT_CONVERGED) return rc_run; // a breakdown still hands back what it has
     if (r) {
         const std::string keep = ctx->err;
         if (int rc = mag_download(ctx, r)) return rc;

@@ -97,6 +97,10 @@ __device__ inline int cg_step(CgState *st, long long k, double rr, double rrh0, 
     const bool maxed = k >= st->max_iter;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (k >= 1 && k - 1 < hist_len) hist[k - 1] = cost;
+        if (k >= 1 && cost < st->best_cost) { // argmin's state.update(): best_param follows the lowest cost
+            st->best_cost = cost;
+            st->best_iter = k;
+        }
         if (finished || broke || maxed) {
             st->iterations = k;
             st->final_cost = cost;
@@ -698,6 +702,8 @@ __global__ void __launch_bounds__(256) k_cg_setup(const double *partRR, int nPar
         st->iterations = 0;
         st->max_iter = max_iter;
         st->breakdown = 0;
+        st->best_cost = __builtin_inf();
+        st->best_iter = 0;
         // b == 0: the first alpha would be 0/0; return x = 0 (documented deviation, see oracle orc_cg)
         st->done = (bb == 0.0) ? 1 : 0;
         st->converged = (bb == 0.0) ? 1 : 0;
@@ -855,6 +861,10 @@ __device__ inline bool fused_step(FusedState *st, int par, long long j, double t
     const bool maxed = it_done >= max_iter;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (it_done >= 1 && it_done - 1 < hist_len) hist[it_done - 1] = cost;
+        if (it_done >= 1 && cost < st->best_cost) { // argmin's state.update(): best_param follows the lowest cost
+            st->best_cost = cost;
+            st->best_iter = it_done;
+        }
         if (finished || broke || maxed) {
             st->iterations = it_done < 0 ? 0 : it_done;
             st->final_cost = cost;
@@ -1503,6 +1513,8 @@ __global__ void __launch_bounds__(256) k_fused_setup(const double *part, int nPa
         st->iterations = 0;
         st->max_iter = max_iter;
         st->breakdown = 0;
+        st->best_cost = __builtin_inf();
+        st->best_iter = 0;
         st->done = (bb == 0.0) ? 1 : 0; // b == 0: x = 0 (documented deviation)
         st->converged = (bb == 0.0) ? 1 : 0;
         if (bb == 0.0) st->final_cost = 0.0;

@@ -115,7 +115,9 @@ struct CgState {
     int breakdown;
     int stop_mode;
     double tol;
-    double pad[3];
+    double best_cost;    // lowest cost over iterations 1..k and the iteration that had it: argmin's best_param
+    long long best_iter; // (solver.rs:167-174 returns state.best_param, not the last iterate)
+    double pad[1];
 };
 
 struct OpParams {
@@ -214,7 +216,9 @@ struct FusedState {
     double target, final_cost, bb, tol;
     long long iterations, max_iter;
     int done, converged, breakdown, stop_mode;
-    double pad[6];
+    double best_cost;    // as in CgState
+    long long best_iter;
+    double pad[4];
 };
 struct FusedParams {
     int64_t N;

@@ -493,6 +493,13 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
     long long j = 0;
     int verdict = 0; // 1 converged, 2 iteration cap, 3 non-finite
     double cost = 0.0;
+    // argmin's best_param bookkeeping (solver.rs:167-174): lowest cost so far and the iteration that had it, kept by
+    // the one thread that reports the verdict, in LDS (no registers of the other 511 lanes)
+    const bool reporter = blockIdx.x == 0 && tid == 0;
+    if (reporter) {
+        s_chunk[0] = __builtin_inf();
+        ((long long *)s_chunk)[1] = 0;
+    }
     for (;;) {
         const double S0 = s_S[0], S1 = s_S[1], S2 = s_S[2], S3 = s_S[3];
         if (j == 0) {
@@ -502,11 +509,15 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
         const double rr = S0;
         cost = P.stop_mode == 1 ? fabs(rr) : sqrt(rr);
         const long long it_done = j - 1;
-        if (blockIdx.x == 0 && tid == 0 && it_done >= 1 && it_done - 1 < P.hist_len) P.hist[it_done - 1] = cost;
+        if (reporter && it_done >= 1 && it_done - 1 < P.hist_len) P.hist[it_done - 1] = cost;
         if (j == 0 && bb == 0.0) {
             verdict = 1;
             cost = 0.0;
             break;
+        }
+        if (reporter && it_done >= 1 && cost < s_chunk[0]) {
+            s_chunk[0] = cost;
+            ((long long *)s_chunk)[1] = it_done;
         }
         if (it_done >= 1 && cost <= target) verdict = 1;
         else if (!(fabs(rr) <= 1.79769313486231570e308)) verdict = 3;
@@ -595,6 +606,8 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
         st->final_cost = cost;
         st->converged = verdict == 1 ? 1 : 0;
         st->breakdown = verdict == 3 ? 1 : 0;
+        st->best_cost = s_chunk[0];
+        st->best_iter = ((long long *)s_chunk)[1];
         st->done = 1;
     }
 }

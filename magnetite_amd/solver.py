@@ -192,6 +192,9 @@ class Context:
                     prob.poisson_ratio, prob.part_thickness)
 
     def run(self, allow_not_converged=False):
+        """mag_run.  Stopping at the iteration cap is a normal termination, as in the reference (solver.rs:149-176
+        returns Ok(best_param)): no error, stats()["converged"] == 0, the best iterate is returned.
+        allow_not_converged only tolerates a numerical breakdown (MAG_ERR_NOT_CONVERGED: non-finite residual)."""
         allow = (MAG_ERR_NOT_CONVERGED,) if allow_not_converged else ()
         return self._check(self._L.mag_run(self._h), allow)
 

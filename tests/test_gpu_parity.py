@@ -213,14 +213,28 @@ def test_run_to_run_bitwise_reproducible(built):
     assert np.array_equal(a["u"], b["u"]) and np.array_equal(a["f"], b["f"])
 
 
-def test_max_iter_reports_not_converged(built):
+@pytest.mark.parametrize("variant", [2, 1, 0])
+def test_iteration_cap_returns_best_param_like_argmin(built, variant):
+    """solver.rs:149-176: argmin's MaxItersReached is a normal termination and the reference returns
+    Ok(state.best_param) -- the LOWEST-cost iterate (plain CG's residual norm is not monotone), not the last one.
+    mag_run therefore returns MAG_OK with converged = 0, termination = MAG_TERM_MAX_ITERS, iterations = the cap (what
+    the reference's observer prints) and the iterate of best_iteration; the oracle's orc_cg keeps best_param too."""
     p = PROBLEMS["plate_shuffled"]
-    with Context(device=0, max_iter=10) as c:
-        with pytest.raises(MagnetiteError) as ei:
-            c.solve(p)
-        assert "Conjugate Gradient" in str(ei.value)
-        out = c.solve(p, allow_not_converged=True)
-    assert out["converged"] == 0 and out["iterations"] == 10
+    cap = 50
+    ref = oracle_run(p, max_iter=cap, hist_len=cap)
+    kbest = int(np.argmin(ref["history"])) + 1
+    assert kbest == 41 and ref["iterations"] == cap  # the cap falls into a rising stretch of the residual history
+    with Context(device=0, max_iter=cap, history_len=cap, cg_variant=variant, tile_nodes=512 if variant == 2 else 0) as c:
+        out = c.solve(p)  # no error
+        hist = c.history(cap)
+        assert c.stats()["cg_kernel"] == variant
+    assert out["converged"] == 0 and out["termination"] == _lib.MAG_TERM_MAX_ITERS and out["iterations"] == cap
+    assert out["best_iteration"] == kbest == int(np.argmin(hist)) + 1
+    assert out["final_cost"] == hist[kbest - 1] and abs(out["final_cost"] - ref["final_cost"]) <= 1e-9 * ref["final_cost"]
+    assert rel(out["u"], ref["u"]) <= TOL_U
+    # and it IS a different vector from the last iterate
+    last = oracle_run(p, max_iter=kbest)  # orc_cg stopped at kbest returns x_kbest (its best so far)
+    assert rel(out["u"], last["u"]) <= TOL_U
 
 
 def test_zero_rhs_returns_zero(built):
