@@ -7,10 +7,18 @@ whose flat arrays are already resident in HBM (mag_upload happens before the tim
 
   N = 1 : BASELINE config 3, the configuration the metric is quoted on: ~1M-triangle plate with a hole,
           left edge fixed, right edge ux = delta, CG to relative residual 1e-8.
-  N > 1 : weak scaling -- every GPU owns ~1M triangles of one global plate N times as tall (strips along y,
-          one RCCL all-reduce of [halo residual | dot partials] per CG kernel pair).
+  N > 1 : MUST be started under torch.distributed.run (one process per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+          from the environment):
+              python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+                  bench.py --gpus N --steps K --warmup W
+          weak scaling (default): every GPU owns ~1M triangles of one global plate N times as tall; ranks own contiguous
+          Hilbert-tile ranges; per CG iteration ONE exchange of [dot partials | q on interface nodes].
+          --partition strong: the workload at its BASELINE size split over the N GPUs (configs 4 and 5).
 
 value = elements of the global mesh * steps / wall time of the timed region (max over ranks).
+The line carries `roofline` (dominant kernel: bound, algorithmic bytes or flops per launch / live HIP-event time, peak,
+PMC traffic), `spmv`, `hbm_resident` (the same kernels on the 16M-triangle mesh, beyond the Infinity Cache) and
+`cpu_baseline` (the oracle timed on this host).
 """
 import argparse
 import json
@@ -22,6 +30,39 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.65  # half the guide's 157.3 TFLOP/s fp32 vector peak: 256 CUs x 4 SIMDs x 16 fp64 FMA lanes
+INFINITY_CACHE_BYTES = 256 << 20
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+
+
+def bytes_spmv(E, N):
+    """matrix-free SpMV -- connectivity 12E, coordinates 16N, x read 16N, y write 16N, BC mask 2N."""
+    return 12.0 * E + 50.0 * N
+
+
+def bytes_iteration_unfused(E, N):
+    """one CG iteration as separate passes -- SpMV + dot(p,q) 16n + x-axpy 24n + r-axpy 24n + dot(r,r) 8n +
+    p-update 24n (n = 2N): 12E + 242N.  What a textbook implementation streams; the fused kernel moves less."""
+    return 12.0 * E + 242.0 * N
+
+
+def bytes_iteration_fused(E, N):
+    """What ONE fused launch per iteration must move at the least: every node's r, q, p and x
+    read once and written once (4 x 16 + 4 x 16 = 128N: alpha is known only after the grid-wide reduction, so q of the
+    previous launch has to come back), coordinates 16N, BC mask 1N, connectivity 12E: 12E + 145N."""
+    return 12.0 * E + 145.0 * N
+
+
+def flops_iteration(E, N):
+    """~110 flop per element for the element-loop operator (area, B, D B u_e, B^T sigma A t) + the CG
+    vector work, 2 dots (2n flop each) and 3 axpys (2n each) = 10n = 20N."""
+    return 110.0 * E + 20.0 * N
+
+
+def load_pmc(key):
+    if os.path.exists(PMC_SUMMARY):
+        return json.load(open(PMC_SUMMARY)).get(key)
+    return None
 
 
 def build_problem(workload, n_gpus):
@@ -80,6 +121,79 @@ def cpu_baseline(prob, gpu_iterations, stop_mode, tol, sample_iters):
     }
 
 
+def kernel_line(kernel, nbytes, formula, ms_per_launch, pmc):
+    """HBM-roofline entry of one streaming kernel: algorithmic bytes per launch / live HIP-event time per launch."""
+    gbs = nbytes / (ms_per_launch * 1e-3) / 1e9
+    d = {"kernel": kernel, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": gbs / HBM_PEAK_GBS, "bytes_per_launch": nbytes, "bytes_formula": formula,
+         "us_per_launch": ms_per_launch * 1e3, "traffic": None, "traffic_source": None,
+         # a working set below the 256 MiB Infinity Cache is served on-die across back-to-back launches: the figure is
+         # then a cache-resident rate, not an HBM-resident one (hbm_resident carries that)
+         "working_set_fits_infinity_cache": bool(nbytes < INFINITY_CACHE_BYTES)}
+    if pmc and "hbm_bytes_per_launch" in pmc:
+        d["traffic"] = pmc["hbm_bytes_per_launch"]
+        d["traffic_source"] = "profiles/r02_pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
+    return d
+
+
+def roofline_streaming(kind, E, N, ms_op, pmc, tile):
+    if kind == 1:
+        return kernel_line("k_cg_fused_dma<%d> (whole CG iteration in one launch: r, x, p updates + matrix-free SpMV + "
+                           "4 dot partials)" % tile, bytes_iteration_fused(E, N),
+                           "12E+145N: what one fused launch per iteration must move (DESIGN.md section 5); the unfused "
+                           "iteration of SURVEY 8d would stream 12E+242N", ms_op, pmc)
+    return kernel_line("k_operator_lds<%d> (matrix-free SpMV fused with the p and x updates and p.q)" % tile,
+                       bytes_spmv(E, N) + 48.0 * N, "12E+50N (SpMV, SURVEY 8d) + 48N (p read, p and x written)", ms_op, pmc)
+
+
+def roofline_onchip(E, N, iters, ms_cg, pmc, tile):
+    """k_cg_persist keeps the CG state in registers and LDS: HBM only sees the per-iteration exchange, so an HBM roof
+    says nothing about it.  Its largest counted resource is fp64 vector issue (PMC: SQ_ACTIVE_INST_VALU), so it is
+    priced against the fp64 vector peak with the ALGORITHMIC flops of the iterations it ran; the counted utilisations
+    of every resource (separate rocprofv3 --pmc passes, profiles/r02_pmc_summary.json) ride along."""
+    flops = flops_iteration(E, N) * iters
+    tf = flops / (ms_cg * 1e-3) / 1e12
+    d = {"kernel": "k_cg_persist<%d> (the whole CG solve in ONE launch: state resident in registers and LDS, grid-wide "
+                   "exchange by tagged granules every iteration)" % tile,
+         "bound": "valu-fp64", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+         "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "flops_per_launch": flops,
+         "flops_formula": "(110E + 20N) x iterations (SURVEY 8d: ~110 flop per element-loop SpMV element + 10 flop per "
+                          "DOF of CG vector work); one launch = one solve",
+         "us_per_launch": ms_cg * 1e3, "traffic": None, "traffic_source": None, "counted": None}
+    if pmc:
+        t_it = ms_cg * 1e-3 / max(iters, 1)
+        d["traffic"] = pmc["hbm_bytes_setup"] + pmc["hbm_bytes_per_iteration"] * iters
+        d["traffic_source"] = "profiles/r02_pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE; runs of two lengths)"
+        d["counted"] = dict(pmc.get("utilisation", {}))
+        d["counted"]["hbm_frac_live"] = pmc["hbm_bytes_per_iteration"] / t_it / 1e9 / HBM_PEAK_GBS
+        d["counted"]["source"] = "profiles/r02_pmc_counters.csv, per CG iteration (difference of two run lengths)"
+    return d
+
+
+def hbm_resident_leg(device, reps):
+    """The same two kernels on BASELINE config 5's 16M-triangle mesh, whose working set (0.6 GB SpMV, 1.4 GB iteration)
+    cannot sit in the 256 MiB Infinity Cache: the figure the north star's ">= 40 % of peak HBM bandwidth in the CG
+    SpMV" has to stand on.  No solve (20 000 iterations): mag_time_* only need the symbolic phase."""
+    from magnetite_amd import Context
+    t0 = time.perf_counter()
+    prob, desc = build_problem("multihole16m", 1)
+    E, N = prob.mesh.num_elements, prob.mesh.num_nodes
+    with Context(device=device, cg_variant=1) as c:
+        c.upload_problem(prob)
+        ms_it = c.time_operator(reps)
+        ms_sp = c.time_spmv(reps)
+    tile = 512 if N >= 512 * 512 else 256  # the library's automatic choice (mag_options.tile_nodes = 0)
+    key = f"multihole16m:tile{tile}"
+    return {"workload": f"multihole16m: {desc}, {E} triangles, {N} nodes (BASELINE config 5 geometry, one GPU)",
+            "elements": E, "nodes": N, "tile_nodes": tile, "launches_timed": reps,
+            "spmv": kernel_line("k_operator_lds<%d,false> (plain matrix-free SpMV)" % tile, bytes_spmv(E, N),
+                                "12E+50N (SpMV, SURVEY 8d)", ms_sp, load_pmc(key + ":spmv")),
+            "iteration": kernel_line("k_cg_fused_dma<%d> (whole CG iteration in one launch)" % tile,
+                                     bytes_iteration_fused(E, N), "12E+145N (fused iteration, DESIGN.md section 5)",
+                                     ms_it, load_pmc(key + ":kernel1")),
+            "seconds": time.perf_counter() - t0}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,6 +209,13 @@ def main():
                     help="2: on-chip single-launch CG when the mesh fits the chip (else as 1), 1: one fused launch per CG "
                          "iteration, 0: two launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-resident", action="store_true",
+                    help="N = 1: skip the HBM-resident leg (SpMV and iteration kernel timed on the 16M-triangle mesh)")
+    ap.add_argument("--partition", default="weak", choices=["weak", "strong"],
+                    help="N > 1.  weak (default, the scaling curve): every GPU gets the workload's mesh, stacked N times "
+                         "along y.  strong: the workload at its BASELINE size split over the N GPUs (config 4 = "
+                         "--gpus 4 --workload plate4m --partition strong; config 5 = --gpus 8 --workload multihole16m "
+                         "--partition strong)")
     ap.add_argument("--cpu-sample-iters", type=int, default=1500,
                     help="CG iterations of the 1-thread CPU sample (default ~11 s at 1M triangles; x4 for the OpenMP leg)")
     ap.add_argument("--op-reps", type=int, default=400)
@@ -139,7 +260,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     stop_mode = {"rel": _lib.MAG_STOP_REL, "rnorm": _lib.MAG_STOP_RNORM, "rnorm_sq": _lib.MAG_STOP_RNORM_SQ}[args.stop]
-    prob, desc = build_problem(args.workload, world)
+    prob, desc = build_problem(args.workload, world if args.partition == "weak" else 1)
     E, N = prob.mesh.num_elements, prob.mesh.num_nodes
 
     ctx = Context(device=local_rank, stop_mode=stop_mode, tol=args.tol, tile_nodes=args.tile,
@@ -225,14 +346,25 @@ def main():
         # measured on the one-GPU development box, so the choice is made HERE, before anything is timed: one solve to
         # warm up and one timed solve each way, the faster exchange is kept (every rank sees the same two numbers).
         if open_inboxes():
+            import numpy as np
             ctx.run()
-            t_inbox, k_inbox = timed_solve(), int(ctx.stats()["cg_kernel"])
+            t_inbox, st_in = timed_solve(), ctx.stats()
+            k_inbox, it_inbox = int(st_in["cg_kernel"]), int(st_in["iterations"])
+            u_inbox = ctx.download()[0]
             barrier()
             ctx.close_inboxes()
             ctx.run()
-            t_rccl = timed_solve()
-            autotune = {"s_per_solve_inboxes": t_inbox, "kernel_with_inboxes": k_inbox, "s_per_solve_allreduce": t_rccl}
-            if (args.exchange == "inboxes" or t_inbox < t_rccl) and k_inbox == 2 and open_inboxes():
+            t_rccl, it_rccl = timed_solve(), int(ctx.stats()["iterations"])
+            u_rccl = ctx.download()[0]
+            # the inbox path has never run across two devices before this node: it is kept only if it reproduces the
+            # all-reduce solve (same recurrence, so the same iteration count up to round-off at the threshold, and
+            # displacements within the parity bar) on EVERY rank -- being faster is not enough
+            du = float(np.linalg.norm(u_inbox - u_rccl) / max(np.linalg.norm(u_rccl), 1e-300))
+            same = all_agree(k_inbox == 2 and abs(it_inbox - it_rccl) <= max(2, it_rccl // 1000) and du <= 1e-8)
+            autotune = {"s_per_solve_inboxes": t_inbox, "kernel_with_inboxes": k_inbox, "s_per_solve_allreduce": t_rccl,
+                        "iterations_inboxes": it_inbox, "iterations_allreduce": it_rccl, "rel_l2_u_between_them": du,
+                        "solutions_agree_on_every_rank": same}
+            if same and (args.exchange == "inboxes" or t_inbox < t_rccl) and open_inboxes():
                 exchange = "per-rank inboxes in device memory (HIP IPC), on-chip CG on every rank"
 
     for _ in range(args.warmup):
@@ -251,82 +383,67 @@ def main():
     st = ctx.stats()
     if args.tile == 0:  # what the library chose (mag_options.tile_nodes = 0): the tile size that gives its tile count
         args.tile = next(b for b in (256, 512, 1024) if (N + b - 1) // b == int(st["num_tiles"]))
-    # HIP events on the library's own stream around op_reps back-to-back launches (mag_time_operator / mag_time_spmv)
-    ms_op = ctx.time_operator(args.op_reps)   # the CG iteration kernel (dominant: one launch per iteration)
+    # HIP events on the library's own stream around op_reps back-to-back launches (mag_time_operator / mag_time_spmv);
+    # with several ranks each launch covers the tiles this rank owns (its per-GPU share)
+    ms_op = ctx.time_operator(args.op_reps)   # the streaming CG iteration kernel (one launch per iteration)
     ms_spmv = ctx.time_spmv(args.op_reps)     # the plain matrix-free SpMV y = M K M v
     u, _, _ = ctx.download()
+    comm = ctx.comm_info()
+    fallback = bool(st["persist_timeout"])  # the on-chip kernel was chosen, gave up at its grid barrier, streaming redid it
 
     if rank == 0:
         iters = int(st["iterations"])
         ms_step = elapsed * 1e3 / args.steps
-        Eloc, Nloc = E / world, N / world  # per-GPU share the operator kernel processes per launch
-        spmv_bytes = 12.0 * Eloc + 50.0 * Nloc          # matrix-free SpMV
-        iter_bytes = 12.0 * Eloc + 242.0 * Nloc         # full CG iteration (SpMV + 2 dots + 3 axpy)
+        Eloc, Nloc = E / world, N / world  # per-GPU share: what one launch of the kernels processes
         kind = int(st["cg_kernel"])  # what ran: 2 on-chip single launch, 1 one fused launch per iteration, 0 two launches
+        tile_key = f"{args.workload}:tile{args.tile}"
         if kind == 2:
-            # ONE launch runs the whole CG phase (HIP events around it: stats ms_cg): its algorithmic bytes are the
-            # per-iteration figure times the iterations it performed
-            ms_op = st["ms_cg"]
-            kernel_bytes = iter_bytes * iters
+            roofline = roofline_onchip(Eloc, Nloc, iters, st["ms_cg"], load_pmc(f"{tile_key}:kernel2"), args.tile)
         else:
-            kernel_bytes = iter_bytes if kind == 1 else (12.0 * Eloc + 50.0 * Nloc)
-        achieved = kernel_bytes / (ms_op * 1e-3) / 1e9
-        # mag_time_spmv applies the plain operator to the WHOLE mesh on every rank (it is not partitioned)
-        spmv_bytes = 12.0 * E + 50.0 * N
-        spmv_gbs = spmv_bytes / (ms_spmv * 1e-3) / 1e9
+            roofline = roofline_streaming(kind, Eloc, Nloc, ms_op, load_pmc(f"{tile_key}:kernel{kind}"), args.tile)
+        roofline["us_per_iteration"] = st["ms_cg"] * 1e3 / max(iters, 1)
+        spmv = kernel_line("k_operator_lds<%d,false> (plain matrix-free SpMV y = M K M v)" % args.tile,
+                           bytes_spmv(Eloc, Nloc), "12E+50N (SpMV, SURVEY 8d), per-GPU share", ms_spmv,
+                           load_pmc(f"{tile_key}:spmv"))
         asm_ms = st["ms_element"] + st["ms_assemble"] + st["ms_bc"]
-        traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-        if os.path.exists(pmc):  # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/README.md)
-            pj = json.load(open(pmc))
-            key = f"{args.workload}:tile{args.tile}:kernel{kind}"
-            if key in pj and kind == 2:  # setup + per-iteration traffic, from two PMC runs of different length
-                traffic = pj[key]["hbm_bytes_setup"] + pj[key]["hbm_bytes_per_iteration"] * iters
-                traffic_src = "profiles/r01_pmc_summary.json:" + key
-            elif key in pj:
-                traffic, traffic_src = pj[key]["hbm_bytes_per_launch"], "profiles/r01_pmc_summary.json:" + key
         out = {
             "metric": "elements/sec assembly + CG iters/sec (achieved HBM GB/s), 1M-tri mesh",
             "value": E * args.steps / elapsed, "unit": "elements/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.partition, "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}, {E} triangles, {N} nodes, left edge fixed, "
                                    f"right edge ux=delta; full solver::run per step; CG stop={args.stop} tol={args.tol:g}",
                        "elements": E, "nodes": N, "tile_nodes": args.tile, "cg_variant": args.cg_variant, "cg_kernel": kind, "cg_stop": args.stop, "cg_tol": args.tol,
-                       "parallelism": f"strips{world}" if world > 1 else "single",
-                       "exchange": exchange, "exchange_autotune": autotune},
-            "roofline": {"bound": "hbm",
-                         "kernel": {2: "k_cg_persist<%d> (the whole CG solve in one launch: state resident in registers "
-                                       "and LDS, grid-wide exchange by tagged granules every iteration)" % args.tile,
-                                    1: "k_cg_fused_dma<%d> (whole CG iteration in one launch: r,x,p updates + "
-                                       "matrix-free SpMV + 4 dot partials)" % args.tile,
-                                    0: "k_operator_lds<%d> (matrix-free SpMV fused with p and x updates, p.q)"
-                                       % args.tile}[kind],
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "bytes_per_launch": kernel_bytes,
-                         "bytes_formula": {2: "(12E+242N) x iterations (full CG iteration, SURVEY 8d; one launch = one solve)",
-                                           1: "12E+242N (full CG iteration, SURVEY 8d)",
-                                           0: "12E+50N (SpMV, SURVEY 8d)"}[kind],
-                         "us_per_launch": ms_op * 1e3,
-                         "us_per_iteration": st["ms_cg"] * 1e3 / max(iters, 1),
-                         "note": ("the state never leaves the chip: the fraction compares the bytes an unfused "
-                                  "iteration would stream with the time taken, it is not HBM utilisation")
-                                 if kind == 2 else None},
-            "spmv": {"kernel": "k_operator_lds<%d,false> (plain matrix-free SpMV)" % args.tile, "achieved": spmv_gbs,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": spmv_gbs / HBM_PEAK_GBS,
-                     "bytes_per_launch": spmv_bytes, "us_per_launch": ms_spmv * 1e3},
+                       "parallelism": f"hilbert-tile-ranges{world}" if world > 1 else "single",
+                       "partition": args.partition if world > 1 else None,
+                       "exchange": exchange, "exchange_autotune": autotune,
+                       "ranks": comm["ranks"], "transport": comm["transport"], "rccl_ranks": comm["rccl_ranks"]},
+            "roofline": roofline,
+            "spmv": spmv,
+            "fallback": fallback,
             "cg_iterations": iters, "cg_converged": int(st["converged"]), "cg_final_cost": st["final_cost"],
             "cg_iters_per_sec": iters / (st["ms_cg"] * 1e-3) if st["ms_cg"] > 0 else None,
-            "cg_iteration_gbps": iter_bytes * iters / (st["ms_cg"] * 1e-3) / 1e9 if st["ms_cg"] > 0 else None,
-            "assembly_elements_per_sec": Eloc / (asm_ms * 1e-3) if asm_ms > 0 else None,
+            # the SURVEY 8(d) figure of the metric's name: bytes an UNFUSED iteration streams / time per iteration.  An
+            # equivalent rate, not HBM utilisation (the fused and on-chip kernels move far less): see roofline
+            "cg_iteration_gbps_unfused_equivalent":
+                bytes_iteration_unfused(E, N) * iters / (st["ms_cg"] * 1e-3) / 1e9 if st["ms_cg"] > 0 else None,
+            "assembly_elements_per_sec": E / (asm_ms * 1e-3) if asm_ms > 0 else None,
             "phases_ms": {k: st[k] for k in ("ms_order", "ms_csr_symbolic", "ms_element", "ms_assemble", "ms_bc",
                                              "ms_cg", "ms_post", "ms_total")},
             "u_max": float(abs(u).max()),
         }
+        if world == 1 and not args.no_hbm_resident and args.workload != "multihole16m":
+            ctx.close()  # its buffers are not needed any more; the 16M leg allocates ~5 GB of its own
+            out["hbm_resident"] = hbm_resident_leg(local_rank, args.op_reps)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, iters, stop_mode, args.tol, args.cpu_sample_iters)
             out["cpu_baseline"]["cores_available"] = os.cpu_count()
+            rec = os.path.join(ROOT, "profiles", "r02_cpu_baseline.json")
+            if os.path.exists(rec):  # scripts/cpu_baseline_record.py: BASELINE.md section 2 items 1-3, timed once
+                rj = json.load(open(rec))
+                out["cpu_baseline"]["config1_dense_s"] = rj.get("config1_dense_s")
+                out["cpu_baseline"]["record"] = "profiles/r02_cpu_baseline.json"
         else:
             out["cpu_baseline"] = None
         if args.share_gpu:
@@ -345,6 +462,12 @@ def main():
             shm.unlink()
     if use_dist:
         dist.destroy_process_group()
+    if fallback:
+        # the line above is marked "fallback": true; a run that silently streamed where the on-chip kernel was chosen
+        # must not pass for a result of the default configuration
+        print("bench.py: the on-chip CG kernel timed out at its grid barrier and the streaming kernels redid the "
+              "solve (stats.persist_timeout)", file=sys.stderr, flush=True)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

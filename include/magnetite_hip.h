@@ -226,7 +226,9 @@ int mag_reduce_system(mag_ctx *ctx, int64_t *n_free, int64_t *nnz_ff, int32_t *r
 int mag_apply_operator(mag_ctx *ctx, const double *x, double *y, int32_t masked);
 /* Bench helper: `reps` back-to-back launches of the CG iteration kernel (cg_variant 1: the fused
  * iteration kernel; 0: the operator kernel of the two-launch iteration) on the context's stream
- * between two HIP events; *ms_per_launch = elapsed / reps. */
+ * between two HIP events; *ms_per_launch = elapsed / reps.  Needs an uploaded problem, not a solve: straight after
+ * mag_upload the symbolic phase is run and the vectors are zeroed.  With several ranks the launch covers the tiles
+ * this rank owns (its per-GPU share). */
 int mag_time_operator(mag_ctx *ctx, int32_t reps, double *ms_per_launch);
 /* The same for the plain matrix-free SpMV y = M K M v (no CG update fused in). */
 int mag_time_spmv(mag_ctx *ctx, int32_t reps, double *ms_per_launch);
@@ -236,6 +238,9 @@ int mag_time_spmv(mag_ctx *ctx, int32_t reps, double *ms_per_launch);
 /* rank 0 calls this and broadcasts the bytes out of band (bench.py: torch.distributed) */
 int mag_comm_get_unique_id(void *id_out);
 int mag_comm_init_rccl(mag_ctx *ctx, const void *unique_id, int32_t nranks, int32_t rank);
+/* What the context's communicator is: info[0] = ranks, info[1] = this rank, info[2] = transport (0 none, 1 RCCL,
+ * 2 host callback), info[3] = ranks as RCCL itself reports them (ncclCommCount; 0 without an RCCL communicator). */
+int mag_comm_query(const mag_ctx *ctx, int32_t info[4]);
 /* test transport: sum-all-reduce of a host buffer supplied by the caller (gloo in tests/) */
 typedef int (*mag_allreduce_fn)(void *user, double *host_buf, int64_t count);
 int mag_comm_init_callback(mag_ctx *ctx, int32_t nranks, int32_t rank, mag_allreduce_fn fn, void *user);

@@ -27,7 +27,7 @@ SYMBOLS = [
     "mag_upload", "mag_run", "mag_download", "mag_get_stats", "mag_get_history", "mag_compute_element_area",
     "mag_compute_strain_displacement_matrix", "mag_compute_stress_strain_matrix",
     "mag_element_stiffness", "mag_assemble_csr", "mag_reduce_system", "mag_apply_operator", "mag_time_operator", "mag_time_spmv",
-    "mag_comm_get_unique_id", "mag_comm_init_rccl", "mag_comm_init_callback", "mag_comm_set_window", "mag_comm_inbox_create", "mag_comm_inbox_open",
+    "mag_comm_get_unique_id", "mag_comm_init_rccl", "mag_comm_query", "mag_comm_init_callback", "mag_comm_set_window", "mag_comm_inbox_create", "mag_comm_inbox_open",
 ]
 
 
@@ -116,6 +116,7 @@ def lib():
     L.mag_time_spmv.argtypes = [vp, C.c_int32, dp]
     L.mag_comm_get_unique_id.argtypes = [vp]
     L.mag_comm_init_rccl.argtypes = [vp, vp, C.c_int32, C.c_int32]
+    L.mag_comm_query.argtypes = [vp, ip]
     L.mag_comm_init_callback.argtypes = [vp, C.c_int32, C.c_int32, ALLREDUCE_FN, vp]
     L.mag_comm_set_window.argtypes = [vp, vp, C.c_uint64]
     L.mag_comm_inbox_create.argtypes = [vp, C.c_uint64, vp]

@@ -18,6 +18,7 @@ struct Rccl {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     std::string err;
 };
@@ -40,6 +41,7 @@ Rccl &rccl()
         r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
         r.AllReduce = (decltype(r.AllReduce))dlsym(r.handle, "ncclAllReduce");
         r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
+        r.CommCount = (decltype(r.CommCount))dlsym(r.handle, "ncclCommCount");
         r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
         if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy || !r.GetErrorString)
             r.err = "librccl is missing a required symbol";
@@ -145,6 +147,15 @@ int Comm::allreduce_sum(double *dev_buf, int64_t count, hipStream_t s, std::stri
         return MAG_ERR_STATE;
     }
     return MAG_OK;
+}
+
+int Comm::rccl_count() const
+{
+    if (!nccl) return 0;
+    Rccl &r = rccl();
+    int n = 0;
+    if (!r.CommCount || r.CommCount((ncclComm_t)nccl, &n) != ncclSuccess) return -1;
+    return n;
 }
 
 void Comm::destroy()

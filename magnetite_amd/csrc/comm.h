@@ -30,6 +30,8 @@ struct Comm {
     int allreduce_sum(double *dev_buf, int64_t count, hipStream_t s, std::string &msg);
     // true when allreduce_sum only enqueues work on s (RCCL); false when it synchronises (callback)
     bool stream_ordered() const { return nccl != nullptr; }
+    // ranks of the RCCL communicator as RCCL itself reports them (ncclCommCount); 0 without one, -1 on error
+    int rccl_count() const;
     void destroy();
 };
 

@@ -218,6 +218,166 @@ void assemble_rows(const int32_t *brow, const int32_t *bcol, const int32_t *bptr
                                                         (const double2 *)xy, nu, youngs, thick, kval);
 }
 
+// solver.rs:263-278 + 290-331 per ELEMENT TILE (the shape BASELINE.json's north star names), still atomic-free and
+// bit-exact.  A tile is kAsmNodes consecutive nodes of the Hilbert order -- a compact patch of the mesh -- together
+// with every element incident on them; one workgroup per tile:
+//   phase 1  one thread per (node, incident element) entry of the tile's slice of the incidence table (a contiguous,
+//            coalesced read of `inc`; connectivity and coordinates gathered once per entry): the element's signed
+//            area and the seven quotients of `strain_displacement_mat /= 2.0 * area` (solver.rs:187-230) -- every
+//            true fp64 division of K_e -- go to LDS, with the element's node ids;
+//   phase 2  one thread per 2x2 block (row node i, col node j) of the tile's K rows, consecutive threads on consecutive
+//            blocks of a row: it walks node i's entries IN LDS, in ascending element order (the reference's `+=` order,
+//            solver.rs:299-325), and for every element that also holds j forms rows 2a, 2a+1 of B^T D and the block
+//            ((B^T D) B)[2a..][2b..] * area * thickness with exactly nalgebra's operations (ascending-k sums from the
+//            first product), from the staged quotients: multiplications and additions only.
+// Against k_assemble_rows (one thread per block re-deriving area, B and nine divisions per matching element straight
+// from global memory: ~9 evaluations per element) an element is now evaluated once per incident node of the tile
+// (<= 3), its divisions are out of the block loop, and the block loop reads LDS.  A tile whose entries do not fit
+// the LDS image (a hub node of valence in the hundreds) takes the k_assemble_rows path for its blocks, same bits.
+constexpr int kAsmNodes = 128;  // nodes per assembly tile
+constexpr int kAsmCap = 1024;   // incidence entries staged per tile (8 per node; a gmsh-style mesh has ~6)
+constexpr int kAsmThreads = 256;
+
+__global__ void __launch_bounds__(kAsmThreads) k_assemble_tiles(const int32_t *bcol, const int32_t *bptr,
+                                                                 const int32_t *inc_off, const uint32_t *inc,
+                                                                 const uint32_t *perm, const int32_t *conn,
+                                                                 const double2 *xy, int64_t N, double nu, double youngs,
+                                                                 double thick, double *kval)
+{
+    __shared__ double s_val[8][kAsmCap];    // bd0 bd1 bd2 gd0 gd1 gd2 z area, entry-minor: conflict-free by entry
+    __shared__ int32_t s_nn[3][kAsmCap];    // the element's node ids (caller numbering); corner a in bits 30-31 of [0]
+    __shared__ int32_t s_scan[kAsmNodes + 1]; // exclusive scan of the tile's block counts
+    __shared__ int32_t s_eoff[kAsmNodes + 1]; // the nodes' entry ranges, relative to the tile's first entry
+    const int tid = threadIdx.x;
+    const int64_t g0 = (int64_t)blockIdx.x * kAsmNodes;
+    const int nn_tile = (int)(N - g0 < kAsmNodes ? N - g0 : kAsmNodes);
+    const int32_t q0 = inc_off[g0];
+    const int n_ent = inc_off[g0 + nn_tile] - q0;
+    const bool staged = n_ent <= kAsmCap;
+    double D[9];
+    stress_strain(nu, youngs, D);
+
+    if (tid <= nn_tile) s_eoff[tid] = inc_off[g0 + tid] - q0;
+    if (tid < nn_tile) {
+        const int64_t i = perm[g0 + tid];
+        s_scan[tid + 1] = bptr[i + 1] - bptr[i];
+    }
+    if (tid == 0) s_scan[0] = 0;
+    if (staged)
+        for (int q = tid; q < n_ent; q += kAsmThreads) {
+            const uint32_t v = inc[q0 + q];
+            const uint32_t e = v / 3u;
+            const int32_t n0 = conn[3 * (int64_t)e], n1 = conn[3 * (int64_t)e + 1], n2 = conn[3 * (int64_t)e + 2];
+            const double2 v0 = xy[n0], v1 = xy[n1], v2 = xy[n2];
+            const double area = signed_area(v0.x, v0.y, v1.x, v1.y, v2.x, v2.y);
+            const double d = 2.0 * area;
+            s_val[0][q] = (v1.y - v2.y) / d;
+            s_val[1][q] = (v2.y - v0.y) / d;
+            s_val[2][q] = (v0.y - v1.y) / d;
+            s_val[3][q] = (v2.x - v1.x) / d;
+            s_val[4][q] = (v0.x - v2.x) / d;
+            s_val[5][q] = (v1.x - v0.x) / d;
+            s_val[6][q] = 0.0 / d; // the structural zeros of B after the division
+            s_val[7][q] = area;
+            s_nn[0][q] = n0 | (int32_t)((v - 3u * e) << 30);
+            s_nn[1][q] = n1;
+            s_nn[2][q] = n2;
+        }
+    __syncthreads();
+    if (tid == 0) { // 128 short counts: a serial scan by one lane costs less than the barriers of a parallel one
+        int32_t run = 0;
+        for (int k = 0; k < nn_tile; ++k) {
+            const int32_t c = s_scan[k + 1];
+            s_scan[k + 1] = run + c;
+            run += c;
+        }
+    }
+    __syncthreads();
+    const int nb_tile = s_scan[nn_tile];
+    for (int idx = tid; idx < nb_tile; idx += kAsmThreads) {
+        int lo = 0, hi = nn_tile; // the node n with s_scan[n] <= idx < s_scan[n + 1]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_scan[mid] <= idx) lo = mid; else hi = mid;
+        }
+        const int kpos = idx - s_scan[lo];
+        const int64_t i = perm[g0 + lo];
+        const int32_t p = bptr[i], cnt = s_scan[lo + 1] - s_scan[lo];
+        const int32_t j = bcol[p + kpos];
+        double k00 = 0.0, k01 = 0.0, k10 = 0.0, k11 = 0.0;
+        if (staged) {
+            for (int q = s_eoff[lo]; q < s_eoff[lo + 1]; ++q) {
+                const int32_t w0 = s_nn[0][q];
+                const int32_t nn[3] = {w0 & 0x3fffffff, s_nn[1][q], s_nn[2][q]};
+                if (nn[0] != j && nn[1] != j && nn[2] != j) continue;
+                const int a = (int)((uint32_t)w0 >> 30);
+                const double bd0 = s_val[0][q], bd1 = s_val[1][q], bd2 = s_val[2][q];
+                const double gd0 = s_val[3][q], gd1 = s_val[4][q], gd2 = s_val[5][q];
+                const double z = s_val[6][q], area = s_val[7][q];
+                const double ba = a == 0 ? bd0 : (a == 1 ? bd1 : bd2), ga = a == 0 ? gd0 : (a == 1 ? gd1 : gd2);
+                // rows 2a, 2a+1 of B^T D, as ke_block forms them: columns (ba, z, ga) and (z, ga, ba) of B
+                double Mx[3], My[3];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) {
+                    double sx = ba * D[m];
+                    sx = sx + z * D[3 + m];
+                    sx = sx + ga * D[6 + m];
+                    Mx[m] = sx;
+                    double sy = z * D[m];
+                    sy = sy + ga * D[3 + m];
+                    sy = sy + ba * D[6 + m];
+                    My[m] = sy;
+                }
+#pragma unroll
+                for (int b = 0; b < 3; ++b) { // ascending local column, as the loops of solver.rs:304-322
+                    if (nn[b] != j) continue;
+                    const double bb = b == 0 ? bd0 : (b == 1 ? bd1 : bd2), gb = b == 0 ? gd0 : (b == 1 ? gd1 : gd2);
+                    double t;
+                    t = Mx[0] * bb; t = t + Mx[1] * z;  t = t + Mx[2] * gb; k00 += t * area * thick;
+                    t = Mx[0] * z;  t = t + Mx[1] * gb; t = t + Mx[2] * bb; k01 += t * area * thick;
+                    t = My[0] * bb; t = t + My[1] * z;  t = t + My[2] * gb; k10 += t * area * thick;
+                    t = My[0] * z;  t = t + My[1] * gb; t = t + My[2] * bb; k11 += t * area * thick;
+                }
+            }
+        } else { // oversize tile: every block straight from global memory, the k_assemble_rows arithmetic
+            for (int32_t q = q0 + s_eoff[lo]; q < q0 + s_eoff[lo + 1]; ++q) {
+                const uint32_t v = inc[q];
+                const uint32_t e = v / 3u;
+                const int a = (int)(v - 3u * e);
+                const int32_t n0 = conn[3 * (int64_t)e], n1 = conn[3 * (int64_t)e + 1], n2 = conn[3 * (int64_t)e + 2];
+                if (n0 != j && n1 != j && n2 != j) continue;
+                const double2 v0 = xy[n0], v1 = xy[n1], v2 = xy[n2];
+                const int32_t nn[3] = {n0, n1, n2};
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    if (nn[b] != j) continue;
+                    double c00, c01, c10, c11;
+                    ke_block(v0, v1, v2, a, b, D, thick, c00, c01, c10, c11);
+                    k00 += c00;
+                    k01 += c01;
+                    k10 += c10;
+                    k11 += c11;
+                }
+            }
+        }
+        double *r0 = kval + 4 * (int64_t)p + 2 * kpos;
+        double *r1 = kval + 4 * (int64_t)p + 2 * cnt + 2 * kpos;
+        r0[0] = k00;
+        r0[1] = k01;
+        r1[0] = k10;
+        r1[1] = k11;
+    }
+}
+
+void assemble_tiles(const int32_t *bcol, const int32_t *bptr, const int32_t *inc_off, const uint32_t *inc,
+                    const uint32_t *perm, const int32_t *conn, const double *xy, int64_t N, double nu, double youngs,
+                    double thick, double *kval, hipStream_t s)
+{
+    const int64_t tiles = (N + kAsmNodes - 1) / kAsmNodes;
+    k_assemble_tiles<<<(unsigned)tiles, kAsmThreads, 0, s>>>(bcol, bptr, inc_off, inc, perm, conn, (const double2 *)xy, N,
+                                                             nu, youngs, thick, kval);
+}
+
 // Opt-in preconditioner (the reference has none, solver.rs:142): the node-diagonal 2x2 blocks of
 // K, summed over the incident elements in ascending element order with ke_block -- bitwise the diagonal blocks of
 // the assembled matrix, so the oracle can rebuild the same M from its own K -- then inverted on the free DOFs and

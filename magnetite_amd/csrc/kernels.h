@@ -78,6 +78,11 @@ void assemble_gather(const uint64_t *keys, const uint32_t *vals, const int32_t *
 void assemble_rows(const int32_t *brow, const int32_t *bcol, const int32_t *bptr, int64_t nb, const int32_t *inc_off,
                    const uint32_t *inc, const int32_t *iperm, const int32_t *conn, const double *xy, double nu,
                    double youngs, double thick, double *kval, hipStream_t s);
+// the same per element tile (kAsmNodes nodes of the Hilbert order + their incident elements, one workgroup each): element
+// areas and the divided B entries staged once per (node, element) entry in LDS, blocks gathered from LDS (default)
+void assemble_tiles(const int32_t *bcol, const int32_t *bptr, const int32_t *inc_off, const uint32_t *inc,
+                    const uint32_t *perm, const int32_t *conn, const double *xy, int64_t N, double nu, double youngs,
+                    double thick, double *kval, hipStream_t s);
 // solver.rs:365-404,427-432: b[row] = sum_{known cols, ascending} -(K*u) + f  (0 on prescribed rows),
 // written in Hilbert order: bP[2*iperm[node]+a]
 void rhs_from_csr(const int32_t *bptr, const int32_t *bcol, const double *kval, const uint8_t *u_known,

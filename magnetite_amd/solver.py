@@ -129,6 +129,13 @@ class Context:
         buf = (C.c_uint8 * _lib.MAG_UNIQUE_ID_BYTES).from_buffer_copy(raw)
         self._check(self._L.mag_comm_init_rccl(self._h, C.cast(buf, C.c_void_p), world, rank))
 
+    def comm_info(self):
+        """dict(ranks, rank, transport, rccl_ranks) of the context's communicator (mag_comm_query)."""
+        info = (C.c_int32 * 4)()
+        self._check(self._L.mag_comm_query(self._h, info))
+        return dict(ranks=info[0], rank=info[1], transport={0: "none", 1: "rccl", 2: "callback"}[info[2]],
+                    rccl_ranks=info[3])
+
     def set_window(self, shm):
         """Multi-GPU on-chip CG: `shm` is a multiprocessing.shared_memory.SharedMemory (or None to remove the window)
         that EVERY rank of the node has opened under the same name; see mag_comm_set_window in the header."""

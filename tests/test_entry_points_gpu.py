@@ -11,6 +11,35 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def check_roofline(d):
+    """`roofline.frac` is a fraction of a roof the kernel can actually hit: in (0, 1], = achieved / peak, for whichever
+    kernel ran -- the on-chip CG is priced in algorithmic flops against the fp64 vector peak, the streaming kernels in
+    the bytes a fused iteration must move against the HBM peak."""
+    rf = d["roofline"]
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.0 < rf["frac"] <= 1.0, rf
+    assert "traffic" in rf
+    if d["config"]["cg_kernel"] == 2:
+        assert rf["bound"] == "valu-fp64" and rf["unit"] == "TFLOP/s" and rf["peak"] == 78.65
+        if rf["counted"]:
+            assert 0.0 < rf["counted"]["valu_busy"] <= 1.0 and 0.0 < rf["counted"]["hbm_frac_live"] <= 1.0
+    else:
+        assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    sp = d["spmv"]
+    assert sp["bound"] == "hbm" and 0.0 < sp["frac"] <= 1.0 and abs(sp["frac"] - sp["achieved"] / sp["peak"]) < 1e-12
+
+
+def test_bench_default_config_roofline_is_a_fraction(built):
+    """the DEFAULT line (hole1m, on-chip kernel) -- what the driver records as BENCH: frac in (0, 1]"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-hbm-resident", "--op-reps", "50"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["config"]["cg_kernel"] == 2 and d["fallback"] is False and d["cg_iterations"] == 5389
+    check_roofline(d)
+    assert d["roofline"]["counted"] is not None and d["roofline"]["traffic"] > 0  # profiles/r02_pmc_summary.json
+
+
 def test_bench_prints_one_contract_line(built):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "plate100k", "--steps", "2",
                         "--warmup", "1", "--cpu-sample-iters", "20", "--op-reps", "50"],
@@ -27,10 +56,16 @@ def test_bench_prints_one_contract_line(built):
     assert d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 0 and abs(d["value"] - d["config"]["elements"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
-    rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0.0 < rf["frac"] < 1.0
-    assert "traffic" in rf
+    check_roofline(d)
+    # the HBM-resident leg: the same kernels on the 16M-triangle mesh, beyond the 256 MiB Infinity Cache
+    hr = d["hbm_resident"]
+    assert hr["elements"] > 15_000_000
+    for leg in ("spmv", "iteration"):
+        k = hr[leg]
+        assert k["bound"] == "hbm" and k["peak"] == 8000.0 and not k["working_set_fits_infinity_cache"]
+        assert abs(k["frac"] - k["achieved"] / k["peak"]) < 1e-12 and 0.0 < k["frac"] <= 1.0
+    assert hr["spmv"]["frac"] >= 0.40                # north_star: >= 40 % of peak HBM bandwidth in the CG SpMV
+    assert d["fallback"] is False
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["unit"] == "elements/s" and cb["value"] > 0 and cb["sample"]
     assert d["value"] > 10.0 * cb["value"]          # north_star: >= 10x the CPU solver at 1 GPU
@@ -52,7 +87,7 @@ def test_bench_multi_rank_code_path_on_one_gpu(built, window):
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None and "rehearsal" in d
-    assert d["config"]["parallelism"] == "strips2" and d["config"]["elements"] == 2 * 100352
+    assert d["config"]["parallelism"] == "hilbert-tile-ranges2" and d["config"]["ranks"] == 2 and d["config"]["elements"] == 2 * 100352
     assert d["cg_converged"] == 1 and d["value"] > 0
     if window == "host-window":  # two ranks x ~50 workgroups fit the one GPU side by side: the on-chip CG runs
         assert d["config"]["cg_kernel"] == 2 and "window" in d["config"]["exchange"]
@@ -61,6 +96,9 @@ def test_bench_multi_rank_code_path_on_one_gpu(built, window):
     else:                        # default: one untimed trial each way, the faster kept
         tune = d["config"]["exchange_autotune"]
         assert tune["kernel_with_inboxes"] == 2 and tune["s_per_solve_inboxes"] > 0 and tune["s_per_solve_allreduce"] > 0
+        # the inbox path is only kept when it reproduced the all-reduce solve on every rank
+        assert tune["solutions_agree_on_every_rank"] is True and tune["rel_l2_u_between_them"] <= 1e-8
+        assert abs(tune["iterations_inboxes"] - tune["iterations_allreduce"]) <= 2
         faster = tune["s_per_solve_inboxes"] < tune["s_per_solve_allreduce"]
         assert d["config"]["cg_kernel"] == (2 if faster else 1)
         assert ("inboxes" in d["config"]["exchange"]) == faster
