@@ -219,128 +219,151 @@ void assemble_rows(const int32_t *brow, const int32_t *bcol, const int32_t *bptr
 }
 
 // solver.rs:263-278 + 290-331 per ELEMENT TILE (the shape BASELINE.json's north star names), still atomic-free and
-// bit-exact.  A tile is kAsmNodes consecutive nodes of the Hilbert order -- a compact patch of the mesh -- together
-// with every element incident on them; one workgroup per tile:
-//   phase 1  one thread per (node, incident element) entry of the tile's slice of the incidence table (a contiguous,
-//            coalesced read of `inc`; connectivity and coordinates gathered once per entry): the element's signed
-//            area and the seven quotients of `strain_displacement_mat /= 2.0 * area` (solver.rs:187-230) -- every
-//            true fp64 division of K_e -- go to LDS, with the element's node ids;
-//   phase 2  one thread per 2x2 block (row node i, col node j) of the tile's K rows, consecutive threads on consecutive
-//            blocks of a row: it walks node i's entries IN LDS, in ascending element order (the reference's `+=` order,
-//            solver.rs:299-325), and for every element that also holds j forms rows 2a, 2a+1 of B^T D and the block
-//            ((B^T D) B)[2a..][2b..] * area * thickness with exactly nalgebra's operations (ascending-k sums from the
-//            first product), from the staged quotients: multiplications and additions only.
-// Against k_assemble_rows (one thread per block re-deriving area, B and nine divisions per matching element straight
-// from global memory: ~9 evaluations per element) an element is now evaluated once per incident node of the tile
-// (<= 3), its divisions are out of the block loop, and the block loop reads LDS.  A tile whose entries do not fit
-// the LDS image (a hub node of valence in the hundreds) takes the k_assemble_rows path for its blocks, same bits.
-constexpr int kAsmNodes = 128;  // nodes per assembly tile
-constexpr int kAsmCap = 1024;   // incidence entries staged per tile (8 per node; a gmsh-style mesh has ~6)
-constexpr int kAsmThreads = 256;
+// bit-exact.  A tile is kAsmNodes consecutive nodes of the Hilbert order -- a compact patch of the mesh -- with every
+// element incident on them; one workgroup (two wavefronts) per tile, one thread per ROW NODE i:
+//   * the thread walks node i's incidence entries (element e, corner a) in ascending element order -- the reference's
+//     `+=` order (solver.rs:299-325) -- kAsmBatch at a time: their connectivity triples are gathered together, then
+//     their coordinates, so a thread keeps 16-24 loads in flight instead of one dependent chain per element (measured:
+//     the gathers, not the arithmetic, set this kernel's time);
+//   * per entry the element is evaluated ONCE: signed area, the seven quotients of `strain_displacement_mat /= 2.0 *
+//     area` (solver.rs:187-230: every true fp64 division of K_e), rows 2a and 2a+1 of B^T D -- and from them the three
+//     2x2 blocks ((B^T D) B)[2a..][2b..] * area * thickness, b = 0, 1, 2, each entry with exactly nalgebra's operations
+//     (ascending-k sums from the first product);
+//   * the blocks are added into the row's accumulators, which live in LDS ([slot][thread], 16-byte pieces: conflict-
+//     free), at the position of node n_b among the row's sorted columns; at the end the thread stores its two scalar
+//     CSR rows (two runs of 16 * cnt bytes).
+// Against k_assemble_rows (one thread per block re-deriving area and five divisions per matching element, each row's
+// entries scanned by every block of the row: ~9 evaluations and ~21 entry visits per element) an element is evaluated
+// once per incident node (3) and visited 3 times.  Rows with more than kAsmSlots blocks (valence > 7) do not fit the
+// accumulators: the workgroup finishes them together, one thread per block, with the k_assemble_rows arithmetic --
+// same bits.
+constexpr int kAsmNodes = 128; // row nodes (threads) per tile
+constexpr int kAsmSlots = 8;   // 2x2 blocks a row may hold in its LDS accumulators (valence 6 interior node: 7)
+constexpr int kAsmBatch = 4;   // incidence entries whose gathers a thread issues together (the kernel is latency-bound)
 
-__global__ void __launch_bounds__(kAsmThreads) k_assemble_tiles(const int32_t *bcol, const int32_t *bptr,
-                                                                 const int32_t *inc_off, const uint32_t *inc,
-                                                                 const uint32_t *perm, const int32_t *conn,
-                                                                 const double2 *xy, int64_t N, double nu, double youngs,
-                                                                 double thick, double *kval)
+__device__ inline void asm_entry(const int32_t (&nn)[3], int a, const double2 v0, const double2 v1, const double2 v2,
+                                 const double *D, double thick, const int32_t (&col)[kAsmSlots], double2 *s_top,
+                                 double2 *s_bot, int lane)
 {
-    __shared__ double s_val[8][kAsmCap];    // bd0 bd1 bd2 gd0 gd1 gd2 z area, entry-minor: conflict-free by entry
-    __shared__ int32_t s_nn[3][kAsmCap];    // the element's node ids (caller numbering); corner a in bits 30-31 of [0]
-    __shared__ int32_t s_scan[kAsmNodes + 1]; // exclusive scan of the tile's block counts
-    __shared__ int32_t s_eoff[kAsmNodes + 1]; // the nodes' entry ranges, relative to the tile's first entry
-    const int tid = threadIdx.x;
-    const int64_t g0 = (int64_t)blockIdx.x * kAsmNodes;
-    const int nn_tile = (int)(N - g0 < kAsmNodes ? N - g0 : kAsmNodes);
-    const int32_t q0 = inc_off[g0];
-    const int n_ent = inc_off[g0 + nn_tile] - q0;
-    const bool staged = n_ent <= kAsmCap;
+    const double area = signed_area(v0.x, v0.y, v1.x, v1.y, v2.x, v2.y);
+    const double d = 2.0 * area;
+    const double bd[3] = {(v1.y - v2.y) / d, (v2.y - v0.y) / d, (v0.y - v1.y) / d};
+    const double gd[3] = {(v2.x - v1.x) / d, (v0.x - v2.x) / d, (v1.x - v0.x) / d};
+    const double z = 0.0 / d; // the structural zeros of B after the division
+    const double ba = a == 0 ? bd[0] : (a == 1 ? bd[1] : bd[2]), ga = a == 0 ? gd[0] : (a == 1 ? gd[1] : gd[2]);
+    // rows 2a, 2a+1 of B^T D, as ke_block forms them: columns (ba, z, ga) and (z, ga, ba) of B
+    double Mx[3], My[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        double sx = ba * D[m];
+        sx = sx + z * D[3 + m];
+        sx = sx + ga * D[6 + m];
+        Mx[m] = sx;
+        double sy = z * D[m];
+        sy = sy + ga * D[3 + m];
+        sy = sy + ba * D[6 + m];
+        My[m] = sy;
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) { // ascending local column, as the loops of solver.rs:304-322
+        const double bb = bd[b], gb = gd[b];
+        double t, c00, c01, c10, c11;
+        t = Mx[0] * bb; t = t + Mx[1] * z;  t = t + Mx[2] * gb; c00 = t * area * thick;
+        t = Mx[0] * z;  t = t + Mx[1] * gb; t = t + Mx[2] * bb; c01 = t * area * thick;
+        t = My[0] * bb; t = t + My[1] * z;  t = t + My[2] * gb; c10 = t * area * thick;
+        t = My[0] * z;  t = t + My[1] * gb; t = t + My[2] * bb; c11 = t * area * thick;
+        int kpos = 0; // position of n_b among the row's ascending columns (it is one of them)
+#pragma unroll
+        for (int k = 0; k < kAsmSlots; ++k) kpos += col[k] < nn[b] ? 1 : 0;
+        double2 top = s_top[kpos * kAsmNodes + lane], bot = s_bot[kpos * kAsmNodes + lane];
+        top.x += c00;
+        top.y += c01;
+        bot.x += c10;
+        bot.y += c11;
+        s_top[kpos * kAsmNodes + lane] = top;
+        s_bot[kpos * kAsmNodes + lane] = bot;
+    }
+}
+
+__global__ void __launch_bounds__(kAsmNodes) k_assemble_tiles(const int32_t *bcol, const int32_t *bptr,
+                                                               const int32_t *inc_off, const uint32_t *inc,
+                                                               const uint32_t *perm, const int32_t *conn,
+                                                               const double2 *xy, int64_t N, double nu, double youngs,
+                                                               double thick, double *kval)
+{
+    __shared__ double2 s_top[kAsmSlots * kAsmNodes]; // (k00, k01) of block `slot` of the thread's row
+    __shared__ double2 s_bot[kAsmSlots * kAsmNodes]; // (k10, k11)
+    const int lane = threadIdx.x;
+    const int64_t g = (int64_t)blockIdx.x * kAsmNodes + lane;
     double D[9];
     stress_strain(nu, youngs, D);
-
-    if (tid <= nn_tile) s_eoff[tid] = inc_off[g0 + tid] - q0;
-    if (tid < nn_tile) {
-        const int64_t i = perm[g0 + tid];
-        s_scan[tid + 1] = bptr[i + 1] - bptr[i];
+    int64_t i = -1;
+    int32_t p = 0, cnt = 0;
+    if (g < N) {
+        i = perm[g];
+        p = bptr[i];
+        cnt = bptr[i + 1] - p;
     }
-    if (tid == 0) s_scan[0] = 0;
-    if (staged)
-        for (int q = tid; q < n_ent; q += kAsmThreads) {
-            const uint32_t v = inc[q0 + q];
-            const uint32_t e = v / 3u;
-            const int32_t n0 = conn[3 * (int64_t)e], n1 = conn[3 * (int64_t)e + 1], n2 = conn[3 * (int64_t)e + 2];
-            const double2 v0 = xy[n0], v1 = xy[n1], v2 = xy[n2];
-            const double area = signed_area(v0.x, v0.y, v1.x, v1.y, v2.x, v2.y);
-            const double d = 2.0 * area;
-            s_val[0][q] = (v1.y - v2.y) / d;
-            s_val[1][q] = (v2.y - v0.y) / d;
-            s_val[2][q] = (v0.y - v1.y) / d;
-            s_val[3][q] = (v2.x - v1.x) / d;
-            s_val[4][q] = (v0.x - v2.x) / d;
-            s_val[5][q] = (v1.x - v0.x) / d;
-            s_val[6][q] = 0.0 / d; // the structural zeros of B after the division
-            s_val[7][q] = area;
-            s_nn[0][q] = n0 | (int32_t)((v - 3u * e) << 30);
-            s_nn[1][q] = n1;
-            s_nn[2][q] = n2;
-        }
-    __syncthreads();
-    if (tid == 0) { // 128 short counts: a serial scan by one lane costs less than the barriers of a parallel one
-        int32_t run = 0;
-        for (int k = 0; k < nn_tile; ++k) {
-            const int32_t c = s_scan[k + 1];
-            s_scan[k + 1] = run + c;
-            run += c;
-        }
-    }
-    __syncthreads();
-    const int nb_tile = s_scan[nn_tile];
-    for (int idx = tid; idx < nb_tile; idx += kAsmThreads) {
-        int lo = 0, hi = nn_tile; // the node n with s_scan[n] <= idx < s_scan[n + 1]
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (s_scan[mid] <= idx) lo = mid; else hi = mid;
-        }
-        const int kpos = idx - s_scan[lo];
-        const int64_t i = perm[g0 + lo];
-        const int32_t p = bptr[i], cnt = s_scan[lo + 1] - s_scan[lo];
-        const int32_t j = bcol[p + kpos];
-        double k00 = 0.0, k01 = 0.0, k10 = 0.0, k11 = 0.0;
-        if (staged) {
-            for (int q = s_eoff[lo]; q < s_eoff[lo + 1]; ++q) {
-                const int32_t w0 = s_nn[0][q];
-                const int32_t nn[3] = {w0 & 0x3fffffff, s_nn[1][q], s_nn[2][q]};
-                if (nn[0] != j && nn[1] != j && nn[2] != j) continue;
-                const int a = (int)((uint32_t)w0 >> 30);
-                const double bd0 = s_val[0][q], bd1 = s_val[1][q], bd2 = s_val[2][q];
-                const double gd0 = s_val[3][q], gd1 = s_val[4][q], gd2 = s_val[5][q];
-                const double z = s_val[6][q], area = s_val[7][q];
-                const double ba = a == 0 ? bd0 : (a == 1 ? bd1 : bd2), ga = a == 0 ? gd0 : (a == 1 ? gd1 : gd2);
-                // rows 2a, 2a+1 of B^T D, as ke_block forms them: columns (ba, z, ga) and (z, ga, ba) of B
-                double Mx[3], My[3];
+    const bool fast = g < N && cnt <= kAsmSlots;
+    if (fast) {
+        int32_t col[kAsmSlots];
 #pragma unroll
-                for (int m = 0; m < 3; ++m) {
-                    double sx = ba * D[m];
-                    sx = sx + z * D[3 + m];
-                    sx = sx + ga * D[6 + m];
-                    Mx[m] = sx;
-                    double sy = z * D[m];
-                    sy = sy + ga * D[3 + m];
-                    sy = sy + ba * D[6 + m];
-                    My[m] = sy;
+        for (int k = 0; k < kAsmSlots; ++k) {
+            col[k] = k < cnt ? bcol[p + k] : 0x7fffffff;
+            s_top[k * kAsmNodes + lane] = make_double2(0.0, 0.0);
+            s_bot[k * kAsmNodes + lane] = make_double2(0.0, 0.0);
+        }
+        const int32_t q1 = inc_off[g + 1];
+        for (int32_t q = inc_off[g]; q < q1; q += kAsmBatch) {
+            uint32_t v[kAsmBatch];
+            int32_t nn[kAsmBatch][3];
+            double2 c[kAsmBatch][3];
+#pragma unroll
+            for (int u = 0; u < kAsmBatch; ++u) v[u] = q + u < q1 ? inc[q + u] : 0xffffffffu;
+#pragma unroll
+            for (int u = 0; u < kAsmBatch; ++u)
+                if (v[u] != 0xffffffffu) {
+                    const int3 t = ((const int3 *)conn)[v[u] / 3u]; // one 12-byte load: a third of the address traffic
+                    nn[u][0] = t.x;
+                    nn[u][1] = t.y;
+                    nn[u][2] = t.z;
                 }
 #pragma unroll
-                for (int b = 0; b < 3; ++b) { // ascending local column, as the loops of solver.rs:304-322
-                    if (nn[b] != j) continue;
-                    const double bb = b == 0 ? bd0 : (b == 1 ? bd1 : bd2), gb = b == 0 ? gd0 : (b == 1 ? gd1 : gd2);
-                    double t;
-                    t = Mx[0] * bb; t = t + Mx[1] * z;  t = t + Mx[2] * gb; k00 += t * area * thick;
-                    t = Mx[0] * z;  t = t + Mx[1] * gb; t = t + Mx[2] * bb; k01 += t * area * thick;
-                    t = My[0] * bb; t = t + My[1] * z;  t = t + My[2] * gb; k10 += t * area * thick;
-                    t = My[0] * z;  t = t + My[1] * gb; t = t + My[2] * bb; k11 += t * area * thick;
+            for (int u = 0; u < kAsmBatch; ++u)
+                if (v[u] != 0xffffffffu) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) c[u][k] = xy[nn[u][k]];
                 }
+#pragma unroll
+            for (int u = 0; u < kAsmBatch; ++u)
+                if (v[u] != 0xffffffffu)
+                    asm_entry(nn[u], (int)(v[u] % 3u), c[u][0], c[u][1], c[u][2], D, thick, col, s_top, s_bot, lane);
+        }
+        double *r0 = kval + 4 * (int64_t)p, *r1 = r0 + 2 * cnt;
+#pragma unroll
+        for (int k = 0; k < kAsmSlots; ++k)
+            if (k < cnt) {
+                const double2 top = s_top[k * kAsmNodes + lane], bot = s_bot[k * kAsmNodes + lane];
+                r0[2 * k] = top.x;
+                r0[2 * k + 1] = top.y;
+                r1[2 * k] = bot.x;
+                r1[2 * k + 1] = bot.y;
             }
-        } else { // oversize tile: every block straight from global memory, the k_assemble_rows arithmetic
-            for (int32_t q = q0 + s_eoff[lo]; q < q0 + s_eoff[lo + 1]; ++q) {
+    }
+    // rows that did not fit the accumulators: the whole workgroup, one thread per block, k_assemble_rows arithmetic
+    if (!__syncthreads_or(g < N && !fast)) return;
+    int32_t *s_big = (int32_t *)s_top; // every fast row has been stored: the accumulators are free (5 workgroups of
+    s_big[lane] = (g < N && !fast) ? (int32_t)i : -1; // exactly 32 KiB fit a CU's 160 KiB)
+    __syncthreads();
+    for (int m = 0; m < kAsmNodes; ++m) {
+        const int32_t ib = s_big[m];
+        if (ib < 0) continue; // uniform
+        const int64_t gb_ = (int64_t)blockIdx.x * kAsmNodes + m;
+        const int32_t pb = bptr[ib], cb = bptr[ib + 1] - pb;
+        for (int kpos = lane; kpos < cb; kpos += kAsmNodes) {
+            const int32_t j = bcol[pb + kpos];
+            double k00 = 0.0, k01 = 0.0, k10 = 0.0, k11 = 0.0;
+            for (int32_t q = inc_off[gb_]; q < inc_off[gb_ + 1]; ++q) {
                 const uint32_t v = inc[q];
                 const uint32_t e = v / 3u;
                 const int a = (int)(v - 3u * e);
@@ -359,13 +382,13 @@ __global__ void __launch_bounds__(kAsmThreads) k_assemble_tiles(const int32_t *b
                     k11 += c11;
                 }
             }
+            double *r0 = kval + 4 * (int64_t)pb + 2 * kpos;
+            double *r1 = kval + 4 * (int64_t)pb + 2 * cb + 2 * kpos;
+            r0[0] = k00;
+            r0[1] = k01;
+            r1[0] = k10;
+            r1[1] = k11;
         }
-        double *r0 = kval + 4 * (int64_t)p + 2 * kpos;
-        double *r1 = kval + 4 * (int64_t)p + 2 * cnt + 2 * kpos;
-        r0[0] = k00;
-        r0[1] = k01;
-        r1[0] = k10;
-        r1[1] = k11;
     }
 }
 
@@ -374,8 +397,8 @@ void assemble_tiles(const int32_t *bcol, const int32_t *bptr, const int32_t *inc
                     double thick, double *kval, hipStream_t s)
 {
     const int64_t tiles = (N + kAsmNodes - 1) / kAsmNodes;
-    k_assemble_tiles<<<(unsigned)tiles, kAsmThreads, 0, s>>>(bcol, bptr, inc_off, inc, perm, conn, (const double2 *)xy, N,
-                                                             nu, youngs, thick, kval);
+    k_assemble_tiles<<<(unsigned)tiles, kAsmNodes, 0, s>>>(bcol, bptr, inc_off, inc, perm, conn, (const double2 *)xy, N,
+                                                           nu, youngs, thick, kval);
 }
 
 // Opt-in preconditioner (the reference has none, solver.rs:142): the node-diagonal 2x2 blocks of

@@ -716,7 +716,7 @@ def test_repeated_solves_do_not_grow_device_memory(built):
     assert free_bytes() >= after_first - (1 << 20)
     c.close()
     assert free_bytes() >= base - (8 << 20)
-    assert L.mag_version() == 1
+    assert L.mag_version() == 2
 
 
 def test_timing_hooks_report_plausible_launch_times(built):
