@@ -7,7 +7,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
+#include <array>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -97,6 +100,10 @@ struct mag_ctx {
     // CSR of K (caller numbering)
     int64_t nb = 0;
     DevBuf pk0, pk1, pv0, pv1, head, blk, rowcnt, seg_start, bptr, brow, bcol, kval, ke;
+    // multi-GPU: a rank keeps only the K rows of its own nodes, one ghost layer and the prescribed nodes
+    bool csr_full = true;    // the CSR held now covers every row (one rank, or a test entry point asked for all of K)
+    bool want_full_csr = false; // mag_assemble_csr / mag_reduce_system on a multi-rank context: build all of K
+    DevBuf local_node, ecnt, eoff;
     // reduced system scratch
     DevBuf isfree, fidx, rcnt, rowoff, rp_ff, col_ff, val_ff, b_ff, rp_full, col_full;
     int64_t nf = 0, nz_ff = 0;
@@ -120,6 +127,8 @@ struct mag_ctx {
     size_t win_bytes = 0;
     // ... or, better, one inbox per rank in DEVICE memory, IPC-mapped by the others (mag_comm_inbox_*)
     void *inbox_own = nullptr, *inbox_peer[8] = {};
+    bool inbox_peer_local[8] = {}; // the peer's inbox lives in THIS process (ranks as threads): a plain pointer, not an IPC mapping
+    std::array<uint8_t, MAG_IPC_HANDLE_BYTES> inbox_handle = {};
     size_t inbox_bytes = 0;
     bool inbox_ready = false;
     DevBuf iface_readers;
@@ -457,8 +466,34 @@ int ensure_order(mag_ctx *ctx)
 // ---- symbolic phase 2 + numeric assembly: K in CSR, caller numbering ----
 int csr_symbolic(mag_ctx *ctx)
 {
-    const int64_t N = ctx->N, E = ctx->E, n9 = 9 * E;
+    const int64_t N = ctx->N, E = ctx->E;
+    int64_t n9 = 9 * E;
     hipStream_t s = ctx->stream;
+    // Several ranks: each keeps the rows of its own nodes, of its tiles' halo nodes (one ghost layer: the ghost
+    // recurrences need their right-hand side) and of the prescribed nodes (reactions on every rank, no second
+    // collective): solver.rs:304-322 couples rows only through shared elements, so those rows are complete.  The
+    // pairs are filtered BEFORE the sort, so the pattern sort, K and every pass over it shrink with the rank count.
+    const bool shard = ctx->comm.nranks > 1 && !ctx->want_full_csr;
+    ctx->csr_full = !shard;
+    if (shard) {
+        HIPCHK(ctx->local_node.reserve((size_t)N + 64));
+        HIPCHK(ctx->ecnt.reserve(4 * ((size_t)E + 1)));
+        HIPCHK(ctx->eoff.reserve(4 * ((size_t)E + 1)));
+        HIPCHK(hipMemsetAsync(ctx->local_node.p, 0, (size_t)N, s));
+        std::vector<int32_t> h2(2);
+        HIPCHK(hipMemcpyAsync(&h2[0], ctx->tile_hoff.as<int32_t>() + ctx->t0, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(&h2[1], ctx->tile_hoff.as<int32_t>() + ctx->t1, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        magk::mark_local(ctx->perm.as<uint32_t>(), ctx->maskP.as<uint8_t>(), N, ctx->own0, ctx->own1,
+                         ctx->halo_g.as<int32_t>(), h2[0], h2[1], ctx->local_node.as<uint8_t>(), s);
+        magk::csr_pair_count(ctx->conn.as<int32_t>(), E, ctx->local_node.as<uint8_t>(), ctx->ecnt.as<int32_t>(), s);
+        if (int rc = scan_i32(ctx, ctx->ecnt.as<int32_t>(), ctx->eoff.as<int32_t>(), (size_t)E + 1)) return rc;
+        int32_t h_n = 0;
+        HIPCHK(hipMemcpyAsync(&h_n, ctx->eoff.as<int32_t>() + E, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        n9 = h_n;
+        if (n9 <= 0) return fail(ctx, MAG_ERR_STATE, "rank %d keeps no row of K", ctx->comm.rank);
+    }
     HIPCHK(ctx->pk0.reserve(8 * (size_t)n9));
     HIPCHK(ctx->pk1.reserve(8 * (size_t)n9));
     HIPCHK(ctx->pv0.reserve(4 * (size_t)n9));
@@ -467,7 +502,11 @@ int csr_symbolic(mag_ctx *ctx)
     HIPCHK(ctx->blk.reserve(4 * (size_t)n9));
     HIPCHK(ctx->rowcnt.reserve(4 * ((size_t)N + 1)));
     HIPCHK(ctx->bptr.reserve(4 * ((size_t)N + 1)));
-    magk::csr_pairs(ctx->conn.as<int32_t>(), E, ctx->pk0.as<uint64_t>(), ctx->pv0.as<uint32_t>(), s);
+    if (shard)
+        magk::csr_pairs_local(ctx->conn.as<int32_t>(), E, ctx->local_node.as<uint8_t>(), ctx->eoff.as<int32_t>(),
+                              ctx->pk0.as<uint64_t>(), ctx->pv0.as<uint32_t>(), s);
+    else
+        magk::csr_pairs(ctx->conn.as<int32_t>(), E, ctx->pk0.as<uint64_t>(), ctx->pv0.as<uint32_t>(), s);
     if (int rc = sort_u64(ctx, ctx->pk0.as<uint64_t>(), ctx->pk1.as<uint64_t>(), ctx->pv0.as<uint32_t>(),
                           ctx->pv1.as<uint32_t>(), (size_t)n9, 32 + ctx->bitsN))
         return rc;
@@ -529,12 +568,17 @@ int gather_phase(mag_ctx *ctx)
     return MAG_OK;
 }
 
+// all of K, for the entry points that hand K out (mag_assemble_csr, mag_reduce_system): a multi-rank context whose run
+// kept only its own rows builds the whole matrix here
 int ensure_csr(mag_ctx *ctx)
 {
-    if (ctx->have_csr) return MAG_OK;
+    if (ctx->have_csr && ctx->csr_full) return MAG_OK;
     if (int rc = ensure_order(ctx)) return rc; // validates conn
-    if (int rc = csr_symbolic(ctx)) return rc;
-    if (int rc = gather_phase(ctx)) return rc;
+    ctx->want_full_csr = true;
+    int rc = csr_symbolic(ctx);
+    ctx->want_full_csr = false;
+    if (rc) return rc;
+    if ((rc = gather_phase(ctx))) return rc;
     ctx->have_csr = true;
     return MAG_OK;
 }
@@ -1075,6 +1119,17 @@ int cg_phase_persist(mag_ctx *ctx)
         // every rank's kernel must be running before anybody's spin budget runs out: line the streams up first
         if (!getenv("MAG_TUNE_PERSIST_SPIN")) P.spin_limit = 1u << 21; // ranks start apart: a longer budget
         std::string msg;
+        // Nothing of an earlier use may look current: a window handed over from another context, or slots of the solve
+        // 255 sequence numbers ago, could carry this solve's tags.  Every rank clears the extent of ITS inbox this solve
+        // will use (rank 0 the shared host window) before the line-up all-reduce: nobody stores into an inbox before
+        // every rank has passed that all-reduce, i.e. after every clear.
+        {
+            const size_t used = 64 + 128 * (size_t)R + 64 * (size_t)ctx->n_iface;
+            if (ctx->inbox_ready)
+                HIPCHK(hipMemsetAsync(ctx->inbox_own, 0, used, s));
+            else if (ctx->comm.rank == 0)
+                HIPCHK(hipMemsetAsync(ctx->win_dev, 0, used, s));
+        }
         HIPCHK(hipMemsetAsync(ctx->comm_pq.p, 0, 8, s));
         if (int rc = ctx->comm.allreduce_sum(ctx->comm_pq.as<double>(), 1, s, msg)) return fail(ctx, rc, "%s", msg.c_str());
     }
@@ -1413,11 +1468,23 @@ mag_ctx *mag_create(const mag_options *opt)
     return ctx;
 }
 
+// Inboxes created in THIS process, by their IPC handle: ranks may be threads of one process (one context each, on one
+// GPU or several), and HIP does not open an IPC handle in the process that exported it -- such a peer is reached
+// through the pointer itself.
+static std::mutex g_inbox_mu;
+static std::map<std::array<uint8_t, MAG_IPC_HANDLE_BYTES>, void *> g_inbox_here;
+
 static void inbox_release(mag_ctx *ctx)
 {
     for (int r = 0; r < 8; ++r) {
-        if (ctx->inbox_peer[r] && ctx->inbox_peer[r] != ctx->inbox_own) (void)hipIpcCloseMemHandle(ctx->inbox_peer[r]);
+        if (ctx->inbox_peer[r] && ctx->inbox_peer[r] != ctx->inbox_own && !ctx->inbox_peer_local[r])
+            (void)hipIpcCloseMemHandle(ctx->inbox_peer[r]);
         ctx->inbox_peer[r] = nullptr;
+        ctx->inbox_peer_local[r] = false;
+    }
+    if (ctx->inbox_own) {
+        std::lock_guard<std::mutex> lk(g_inbox_mu);
+        g_inbox_here.erase(ctx->inbox_handle);
     }
     if (ctx->inbox_own) (void)hipFree(ctx->inbox_own);
     ctx->inbox_own = nullptr;
@@ -1912,6 +1979,11 @@ int mag_comm_inbox_create(mag_ctx *ctx, uint64_t bytes, void *handle_out)
         return fail(ctx, MAG_ERR_HIP, "hipIpcGetMemHandle failed: %s", hipGetErrorString(e));
     }
     memcpy(handle_out, &h, sizeof h);
+    memcpy(ctx->inbox_handle.data(), &h, sizeof h);
+    {
+        std::lock_guard<std::mutex> lk(g_inbox_mu);
+        g_inbox_here[ctx->inbox_handle] = ctx->inbox_own;
+    }
     ctx->inbox_bytes = (size_t)bytes;
     return MAG_OK;
 }
@@ -1929,6 +2001,21 @@ int mag_comm_inbox_open(mag_ctx *ctx, const void *handles)
         }
         hipIpcMemHandle_t h;
         memcpy(&h, (const uint8_t *)handles + (size_t)r * sizeof h, sizeof h);
+        {
+            std::array<uint8_t, MAG_IPC_HANDLE_BYTES> key;
+            memcpy(key.data(), &h, sizeof h);
+            std::lock_guard<std::mutex> lk(g_inbox_mu);
+            const auto it = g_inbox_here.find(key);
+            if (it != g_inbox_here.end()) { // that rank is a thread of this process
+                ctx->inbox_peer[r] = it->second;
+                ctx->inbox_peer_local[r] = true;
+                hipPointerAttribute_t at;
+                if (hipPointerGetAttributes(&at, it->second) == hipSuccess && at.device != ctx->device)
+                    (void)hipDeviceEnablePeerAccess(at.device, 0); // already enabled is fine
+                (void)hipGetLastError();
+                continue;
+            }
+        }
         const hipError_t e = hipIpcOpenMemHandle(&ctx->inbox_peer[r], h, hipIpcMemLazyEnablePeerAccess);
         if (e != hipSuccess) {
             ctx->inbox_peer[r] = nullptr;

@@ -304,7 +304,9 @@ __global__ void __launch_bounds__(kAsmNodes) k_assemble_tiles(const int32_t *bco
         p = bptr[i];
         cnt = bptr[i + 1] - p;
     }
-    const bool fast = g < N && cnt <= kAsmSlots;
+    // cnt == 0: a row this rank does not keep (several GPUs: csr_symbolic filtered its pairs out); every kept row
+    // holds at least its diagonal block
+    const bool fast = g < N && cnt > 0 && cnt <= kAsmSlots;
     if (fast) {
         int32_t col[kAsmSlots];
 #pragma unroll
@@ -351,9 +353,9 @@ __global__ void __launch_bounds__(kAsmNodes) k_assemble_tiles(const int32_t *bco
             }
     }
     // rows that did not fit the accumulators: the whole workgroup, one thread per block, k_assemble_rows arithmetic
-    if (!__syncthreads_or(g < N && !fast)) return;
+    if (!__syncthreads_or(g < N && cnt > kAsmSlots)) return;
     int32_t *s_big = (int32_t *)s_top; // every fast row has been stored: the accumulators are free (5 workgroups of
-    s_big[lane] = (g < N && !fast) ? (int32_t)i : -1; // exactly 32 KiB fit a CU's 160 KiB)
+    s_big[lane] = (g < N && cnt > kAsmSlots) ? (int32_t)i : -1; // exactly 32 KiB fit a CU's 160 KiB)
     __syncthreads();
     for (int m = 0; m < kAsmNodes; ++m) {
         const int32_t ib = s_big[m];

@@ -50,6 +50,13 @@ void fill_ell16(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn
 void halo_coords(const int32_t *halo_g, const double *xyP, int64_t n, double *halo_xy, hipStream_t s);
 // CSR pattern: 9 (row node, col node) pairs per element, key = row<<32 | col, val = 9e + 3a + b
 void csr_pairs(const int32_t *conn, int64_t E, uint64_t *keys, uint32_t *vals, hipStream_t s);
+// multi-GPU: local[i] = 1 for the nodes whose K rows this rank keeps (owned, one ghost layer, prescribed nodes) ...
+void mark_local(const uint32_t *perm, const uint8_t *maskP, int64_t N, int32_t own0, int32_t own1,
+                const int32_t *halo_g, int32_t h0, int32_t h1, uint8_t *local, hipStream_t s);
+// ... cnt[e] = pairs element e contributes to local rows (cnt[E] = 0), and the pairs themselves, compacted at off[e]
+void csr_pair_count(const int32_t *conn, int64_t E, const uint8_t *local, int32_t *cnt, hipStream_t s);
+void csr_pairs_local(const int32_t *conn, int64_t E, const uint8_t *local, const int32_t *off, uint64_t *keys,
+                     uint32_t *vals, hipStream_t s);
 // head[k] = 1 where sorted key k starts a new (row,col) block
 void csr_heads(const uint64_t *keys, int64_t n, int32_t *head, hipStream_t s);
 // for heads: seg_start[blk] = k, brow/bcol[blk] = row/col node, rowcnt[row node]++   (blk = exclusive scan of head)

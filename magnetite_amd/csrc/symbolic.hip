@@ -470,6 +470,66 @@ void csr_pairs(const int32_t *conn, int64_t E, uint64_t *keys, uint32_t *vals, h
     k_csr_pairs<<<blocks_for(9 * E, 256), 256, 0, s>>>(conn, 9 * E, keys, vals);
 }
 
+// ---- multi-GPU: the pattern of the rows a rank keeps (owned nodes, one ghost layer, prescribed nodes) ----
+// local[i] (caller numbering) = 1 for: nodes of the rank's own Hilbert range, halo nodes of its tiles (their rows give
+// the right-hand side of the ghost recurrences), and every node with a prescribed displacement (their rows give the
+// reactions, solver.rs:456-469, on every rank without a second collective; they are boundary nodes: O(sqrt N)).
+__global__ void __launch_bounds__(256) k_mark_local(const uint32_t *perm, const uint8_t *maskP, int64_t N, int32_t own0,
+                                                    int32_t own1, const int32_t *halo_g, int32_t h0, int32_t h1,
+                                                    uint8_t *local)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < N && ((k >= own0 && k < own1) || (maskP[k] & 3))) local[perm[k]] = 1;
+    if (k < h1 - h0) local[perm[halo_g[h0 + k]]] = 1;
+}
+
+void mark_local(const uint32_t *perm, const uint8_t *maskP, int64_t N, int32_t own0, int32_t own1,
+                const int32_t *halo_g, int32_t h0, int32_t h1, uint8_t *local, hipStream_t s)
+{
+    const int64_t n = N > h1 - h0 ? N : h1 - h0;
+    k_mark_local<<<blocks_for(n, 256), 256, 0, s>>>(perm, maskP, N, own0, own1, halo_g, h0, h1, local);
+}
+
+// pairs (row node, col node) an element contributes to LOCAL rows: 3 per local corner
+__global__ void __launch_bounds__(256) k_csr_pair_count(const int32_t *conn, int64_t E, const uint8_t *local,
+                                                        int32_t *cnt)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e > E) return;
+    cnt[e] = e < E ? 3 * ((int)local[conn[3 * e]] + (int)local[conn[3 * e + 1]] + (int)local[conn[3 * e + 2]]) : 0;
+}
+
+// the same keys and values k_csr_pairs emits, for local rows only, compacted in element order (off = scan of the counts)
+__global__ void __launch_bounds__(256) k_csr_pairs_local(const int32_t *conn, int64_t E, const uint8_t *local,
+                                                         const int32_t *off, uint64_t *keys, uint32_t *vals)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int32_t n[3] = {conn[3 * e], conn[3 * e + 1], conn[3 * e + 2]};
+    int32_t o = off[e];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (!local[n[a]]) continue;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            keys[o] = ((uint64_t)(uint32_t)n[a] << 32) | (uint64_t)(uint32_t)n[b];
+            vals[o] = (uint32_t)(9 * e + 3 * a + b);
+            ++o;
+        }
+    }
+}
+
+void csr_pair_count(const int32_t *conn, int64_t E, const uint8_t *local, int32_t *cnt, hipStream_t s)
+{
+    k_csr_pair_count<<<blocks_for(E + 1, 256), 256, 0, s>>>(conn, E, local, cnt);
+}
+
+void csr_pairs_local(const int32_t *conn, int64_t E, const uint8_t *local, const int32_t *off, uint64_t *keys,
+                     uint32_t *vals, hipStream_t s)
+{
+    k_csr_pairs_local<<<blocks_for(E, 256), 256, 0, s>>>(conn, E, local, off, keys, vals);
+}
+
 __global__ void __launch_bounds__(256) k_csr_heads(const uint64_t *keys, int64_t n, int32_t *head)
 {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;

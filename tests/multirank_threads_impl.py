@@ -1,0 +1,154 @@
+"""(run by tests/test_multirank_threads_gpu.py in a process of its own) EIGHT ranks on the one GPU of the test box -- the rank count of BASELINE configs 4/5 and of the driver's
+scaling run -- as eight THREADS of this process, one mag_ctx (one stream) each.
+
+The GPU box admits at most six processes on its card, so the process-per-rank rehearsals of test_distributed_gpu.py
+stop at four ranks; mag_ctx is documented as usable from distinct threads, and the library reaches an inbox created in
+its own process through the pointer itself (HIP does not open an IPC handle in the exporting process), so the whole
+multi-rank path runs here with real library code at R = 8: tile-range partition, interface list with an 8-bit reader
+mask, the exchange buffer of the streaming protocol, the on-chip kernels of all eight ranks co-resident and exchanging
+through per-rank inboxes, the collective fall-back agreement, and the sharded assembly (every rank keeps only the K
+rows of its own nodes, one ghost layer and the prescribed nodes).  What it cannot show is the part that needs a node:
+RCCL between devices and stores crossing xGMI.
+
+Geometry: bench.py's weak-scaling mesh for --gpus 8 (plate-with-hole stacked 8 times along y) at reduced resolution.
+The sum-all-reduce between the threads is done on the host, in rank order, by one thread: the same bits for everybody.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+from magnetite_amd import Context, _lib, meshgen
+
+pytestmark = pytest.mark.gpu
+R = 8
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / max(np.linalg.norm(b), 1e-300))
+
+
+def stacked_problem(n=110, copies=R):
+    holes = [(0.5, (k + 0.5) / copies, 0.15) for k in range(copies)]
+    return meshgen.config_fixed_left_pull_right(
+        meshgen.plate_with_holes(n, n * copies, 1.0, float(copies), holes=holes))
+
+
+class HostAllReduce:
+    """sum-all-reduce between R threads: everybody deposits its view, rank 0 adds them in rank order, everybody copies"""
+
+    def __init__(self, ranks):
+        self.slots = [None] * ranks
+        self.barrier = threading.Barrier(ranks, timeout=180)
+        self.total = None
+
+    def __call__(self, rank, arr):
+        self.slots[rank] = arr
+        self.barrier.wait()
+        if rank == 0:
+            t = self.slots[0].copy()
+            for other in self.slots[1:]:
+                t += other
+            self.total = t
+        self.barrier.wait()
+        arr[:] = self.total
+        self.barrier.wait()
+
+
+def run_ranks(prob, inboxes, solves=1, **opts):
+    comm = HostAllReduce(R)
+    sync = threading.Barrier(R, timeout=180)
+    handles, results, errors = [None] * R, [None] * R, []
+
+    def worker(rank):
+        try:
+            with Context(device=0, **opts) as c:
+                c.init_callback(lambda a, r=rank: comm(r, a), rank, R)
+                if inboxes:
+                    handles[rank] = c.create_inbox(1 << 20)
+                    sync.wait()
+                    c.open_inboxes(handles)
+                outs = []
+                for _ in range(solves):
+                    out = c.solve(prob)
+                    out.update(comm_info=c.comm_info())
+                    outs.append(out)
+                results[rank] = outs
+                sync.wait()  # nobody frees an inbox another rank's kernel may still touch
+        except Exception as exc:  # a failing rank must not leave the others waiting for ever
+            errors.append((rank, repr(exc)))
+            comm.barrier.abort()
+            sync.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(R)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    assert all(r is not None for r in results)
+    return results
+
+
+@pytest.fixture(scope="module")
+def case(built):
+    p = stacked_problem()
+    ref = oracle.run(p.xy_flat, p.conn_flat, p.u_known, p.u_in, p.f_in, p.youngs_modulus, p.poisson_ratio,
+                     p.part_thickness, path="sparse")
+    with Context(device=0) as c:
+        single = c.solve(p)
+    return p, ref, single
+
+
+def check(case, results, kernel):
+    p, ref, single = case
+    k = p.u_known == 1
+    for rank, outs in enumerate(results):
+        for out in outs:
+            assert out["converged"] == 1 and out["cg_kernel"] == kernel, (rank, out["cg_kernel"])
+            assert out["comm_info"]["ranks"] == R and out["comm_info"]["rank"] == rank
+            assert abs(out["iterations"] - ref["iterations"]) <= max(3, ref["iterations"] // 50)
+            assert rel(out["u"], ref["u"]) <= 1e-8 and rel(out["u"], single["u"]) <= 1e-9
+            assert np.array_equal(out["u"][k], p.u_in[k]) and np.array_equal(out["f"][~k], p.f_in[~k])
+            # reactions and stress come from the rank's OWN rows of K (prescribed nodes are kept by every rank) and the
+            # gathered displacements
+            assert rel(out["f"][k], ref["f"][k]) <= 1e-7 and rel(out["stress"], ref["stress"]) <= 1e-7
+            # sharded assembly: a rank holds about an eighth of K plus ghost and boundary rows, never all of it
+            assert 0 < out["nnz"] < 0.3 * single["nnz"], (rank, out["nnz"], single["nnz"])
+        assert all(np.array_equal(o["u"], outs[0]["u"]) for o in outs[1:])  # repeated solves: same bits
+    for outs in results[1:]:  # every rank returns the same full solution, bit for bit
+        assert np.array_equal(outs[0]["u"], results[0][0]["u"]) and np.array_equal(outs[0]["f"], results[0][0]["f"])
+    assert sum(outs[0]["nnz"] for outs in results) >= single["nnz"]
+
+
+def test_eight_ranks_streaming_kernels_one_allreduce_per_iteration(case):
+    check(case, run_ranks(case[0], inboxes=False, cg_variant=1, tile_nodes=512), kernel=1)
+
+
+def test_eight_ranks_on_chip_kernels_exchange_through_inboxes(case):
+    """22-23 tiles per rank, one workgroup each: the eight persistent launches are co-resident on the 256 CUs and meet
+    every iteration through their inboxes; two solves in a row (fresh tags, inboxes cleared between them)"""
+    check(case, run_ranks(case[0], inboxes=True, solves=2, cg_variant=2, tile_nodes=512), kernel=2)
+
+
+def test_eight_ranks_agree_to_fall_back(case, monkeypatch):
+    """MAG_TUNE_PERSIST_SPIN=0: every wait of the on-chip kernels gives up at once; the ranks agree on it through one
+    all-reduce of their failure flags and all redo the solve with the streaming kernels -- and say so in their stats"""
+    monkeypatch.setenv("MAG_TUNE_PERSIST_SPIN", "0")
+    results = run_ranks(case[0], inboxes=True, cg_variant=2, tile_nodes=512)
+    check(case, results, kernel=1)
+    assert all(outs[0]["persist_timeout"] == 1 for outs in results)
+
+
+def test_full_matrix_is_still_available_on_a_multi_rank_context(case):
+    """mag_assemble_csr on a rank of a multi-rank communicator hands out ALL of K (the run itself kept only the rank's
+    rows): bit-identical to the oracle's"""
+    p = case[0]
+    K = oracle.assemble_sparse(p.xy_flat, p.conn_flat, p.poisson_ratio, p.youngs_modulus, p.part_thickness)
+    comm = HostAllReduce(1)
+    with Context(device=0, tile_nodes=512) as c:
+        c.init_callback(lambda a: comm(0, a), 3, R)  # rank 3 of 8; nothing below needs a collective
+        c.upload_problem(p)
+        rowptr, col, val = c.assemble_csr()
+    assert np.array_equal(rowptr.astype(np.int64), K.rowptr) and np.array_equal(col, K.col) and np.array_equal(val, K.val)

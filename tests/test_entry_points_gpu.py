@@ -104,6 +104,24 @@ def test_bench_multi_rank_code_path_on_one_gpu(built, window):
         assert ("inboxes" in d["config"]["exchange"]) == faster
 
 
+def test_bench_strong_partition_keeps_the_baseline_size(built):
+    """--partition strong: the workload at its BASELINE size split over the ranks (configs 4 and 5 are `--gpus 4
+    --workload plate4m --partition strong` and `--gpus 8 --workload multihole16m --partition strong`); rehearsed with
+    two ranks on the one GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu",
+           "--workload", "plate100k", "--steps", "1", "--warmup", "1", "--op-reps", "20", "--exchange", "allreduce",
+           "--partition", "strong"]
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["elements"] == 100352
+    assert d["config"]["partition"] == "strong" and d["config"]["ranks"] == 2 and d["cg_converged"] == 1
+    # per-GPU kernel figures: each rank's launch covers its half of the tiles
+    assert d["spmv"]["bytes_per_launch"] == 12.0 * 100352 / 2 + 50.0 * 50625 / 2
+
+
 def test_smoke_entry_point(built):
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, capture_output=True,
                        text=True, timeout=900)
