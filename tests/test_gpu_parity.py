@@ -720,16 +720,20 @@ def test_repeated_solves_do_not_grow_device_memory(built):
 
 
 def test_timing_hooks_report_plausible_launch_times(built):
-    """mag_time_operator / mag_time_spmv (the HIP-event figures bench.py turns into roofline fractions): they need a
-    completed run, return positive per-launch times, the whole-iteration kernel costs more than the plain SpMV and
+    """mag_time_operator / mag_time_spmv (the HIP-event figures bench.py turns into roofline fractions): they need an
+    uploaded problem, not a solve (bench.py's HBM-resident leg times the 16M-triangle mesh without its 20 000
+    iterations); they return positive per-launch times, the whole-iteration kernel costs more than the plain SpMV and
     neither is faster than the 8 TB/s HBM peak allows for the bytes it must move."""
     p = meshgen.config_fixed_left_pull_right(meshgen.plate_with_holes(300))
     with Context(device=0, stop_mode=MAG_STOP_REL, tol=1e-6) as c:
-        c.upload_problem(p)
         with pytest.raises(MagnetiteError):
-            c.time_operator(10)
+            c.time_operator(10)                   # nothing uploaded
+        c.upload_problem(p)
+        cold_it, cold_mv = c.time_operator(10), c.time_spmv(10)   # straight after the upload: symbolic phase only
+        assert cold_it > 0 and cold_mv > 0
         c.run()
         us_it = c.time_operator(50) * 1e3
+        assert 0.5 < cold_it * 1e3 / us_it < 2.0
         us_mv = c.time_spmv(50) * 1e3
         u1 = c.download()[0]
         c.run()                                  # the hooks run on scratch state: a later solve is unaffected
