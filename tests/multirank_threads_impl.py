@@ -117,6 +117,9 @@ def check(case, results, kernel):
             # sharded assembly: a rank holds about an eighth of K plus ghost and boundary rows, never all of it
             assert 0 < out["nnz"] < 0.3 * single["nnz"], (rank, out["nnz"], single["nnz"])
         assert all(np.array_equal(o["u"], outs[0]["u"]) for o in outs[1:])  # repeated solves: same bits
+    us = [o["ms_cg"] * 1e3 / max(1, o["iterations"]) for outs in results for o in outs]
+    print(f"[{R} ranks, cg_kernel {kernel}] {results[0][0]['iterations']} iterations, {min(us):.2f}-{max(us):.2f} us per "
+          f"iteration; single rank: {single['ms_cg'] * 1e3 / single['iterations']:.2f} us (cg_kernel {single['cg_kernel']})")
     for outs in results[1:]:  # every rank returns the same full solution, bit for bit
         assert np.array_equal(outs[0]["u"], results[0][0]["u"]) and np.array_equal(outs[0]["f"], results[0][0]["f"])
     assert sum(outs[0]["nnz"] for outs in results) >= single["nnz"]
