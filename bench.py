@@ -208,6 +208,9 @@ def main():
     ap.add_argument("--cg-variant", type=int, default=2,
                     help="2: on-chip single-launch CG when the mesh fits the chip (else as 1), 1: one fused launch per CG "
                          "iteration, 0: two launches")
+    ap.add_argument("--precision", default="fp64", choices=["fp64", "fp32"],
+                    help="fp32: the fp32 leg of BASELINE config 5's sweep (CG state and operator in fp32, dots in fp64; "
+                         "streaming kernels; cannot meet the 1e-8 parity bar) -- the line then says dtype f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-resident", action="store_true",
                     help="N = 1: skip the HBM-resident leg (SpMV and iteration kernel timed on the 16M-triangle mesh)")
@@ -264,7 +267,8 @@ def main():
     E, N = prob.mesh.num_elements, prob.mesh.num_nodes
 
     ctx = Context(device=local_rank, stop_mode=stop_mode, tol=args.tol, tile_nodes=args.tile,
-                  check_every=args.check_every, use_graph=0 if args.no_graph else 1, cg_variant=args.cg_variant)
+                  check_every=args.check_every, use_graph=0 if args.no_graph else 1, cg_variant=args.cg_variant,
+                  precision=1 if args.precision == "fp32" else 0)
     if use_dist and args.share_gpu:
         def host_allreduce(arr):
             dist.all_reduce(torch.from_numpy(arr))
@@ -399,6 +403,11 @@ def main():
         tile_key = f"{args.workload}:tile{args.tile}"
         if kind == 2:
             roofline = roofline_onchip(Eloc, Nloc, iters, st["ms_cg"], load_pmc(f"{tile_key}:kernel2"), args.tile)
+        elif kind == 4:  # fp32 leg: value terms halved (r, q, p, x in and out 64N, coordinates 8N, mask 1N); no timing
+            # hook of its own, so the launch time is the CG phase / iterations (graph gaps and early exits included)
+            roofline = kernel_line("k_cg_fused32<%d> (whole CG iteration in one launch, fp32 state)" % args.tile,
+                                   12.0 * Eloc + 73.0 * Nloc, "12E+73N (fused iteration, fp32 values)",
+                                   st["ms_cg"] / max(iters, 1), None)
         else:
             roofline = roofline_streaming(kind, Eloc, Nloc, ms_op, load_pmc(f"{tile_key}:kernel{kind}"), args.tile)
         roofline["us_per_iteration"] = st["ms_cg"] * 1e3 / max(iters, 1)
@@ -410,7 +419,8 @@ def main():
             "metric": "elements/sec assembly + CG iters/sec (achieved HBM GB/s), 1M-tri mesh",
             "value": E * args.steps / elapsed, "unit": "elements/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": args.partition, "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": args.partition, "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "f64",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {desc}, {E} triangles, {N} nodes, left edge fixed, "
                                    f"right edge ux=delta; full solver::run per step; CG stop={args.stop} tol={args.tol:g}",

@@ -113,7 +113,8 @@ typedef struct mag_options {
                              0: two launches per iteration, argmin's recurrences to the letter              */
     int32_t precision;    /* 0 (default): fp64 everywhere, as the reference.  1: the CG state, the operator and
                              (tile-relative) coordinates in fp32, dot products accumulated in fp64 -- the fp32
-                             leg of BASELINE config 5's tolerance sweep; cannot meet the 1e-8 parity bar         */
+                             leg of BASELINE config 5's tolerance sweep; cannot meet the 1e-8 parity bar.  One GPU or
+                             several (streaming protocol: one all-reduce per iteration, exchange buffer in doubles)  */
     int32_t preconditioner; /* 0 (default): plain CG, the reference's iteration (solver.rs:142).  OPT-IN ADDITION with
                              no reference counterpart: 1 Jacobi, 2 block-Jacobi on the 2x2 node-
                              diagonal blocks of K_ff (inverse blocks kept in fp32).  Same stop rule on the true

@@ -1297,10 +1297,11 @@ int cg_phase_fused32(mag_ctx *ctx)
 {
     using magk::FusedState;
     hipStream_t s = ctx->stream;
-    if (!ctx->use_lds || ctx->dist || ctx->B == 1024)
-        return fail(ctx, MAG_ERR_BAD_ARGS, "precision fp32 needs the LDS-halo operator, tile_nodes 256|512 and one GPU");
+    if (!ctx->use_lds || ctx->B == 1024)
+        return fail(ctx, MAG_ERR_BAD_ARGS, "precision fp32 needs the LDS-halo operator and tile_nodes 256|512");
     const int64_t N = ctx->N;
     const int32_t stride = magk::kMaxGrid;
+    const bool dist = ctx->dist;
     HIPCHK(ctx->xy32.reserve(8 * (size_t)N));
     HIPCHK(ctx->hxy32.reserve(8 * (size_t)std::max<int64_t>(ctx->halo_total, 1)));
     HIPCHK(ctx->rqp32a.reserve(sizeof(magk::Rqp32) * (size_t)N));
@@ -1310,12 +1311,37 @@ int cg_phase_fused32(mag_ctx *ctx)
     HIPCHK(ctx->fstate.reserve(sizeof(FusedState)));
     magk::coords32(ctx->xyP.as<double>(), ctx->halo_g.as<int32_t>(), ctx->tile_hoff.as<int32_t>(), N, ctx->B, ctx->T,
                    ctx->xy32.as<float>(), ctx->hxy32.as<float>(), s);
-    const int grid = magk::fused32_grid(ctx->B, ctx->cap, ctx->T);
-    HIPCHK(hipMemsetAsync(ctx->fpart.p, 0, 8 * 2 * 4 * (size_t)stride, s));
-    magk::fused32_init(ctx->bP.as<double2>(), ctx->rqp32a.as<magk::Rqp32>(), ctx->rqp32b.as<magk::Rqp32>(),
-                       ctx->x32.as<float2>(), N, ctx->B, ctx->T, ctx->fpart.as<double>(), stride, grid, s);
-    magk::fused_setup(ctx->fpart.as<double>(), grid, stride, ctx->opt.stop_mode, ctx->opt.tol,
-                      (long long)ctx->opt.max_iter, ctx->fstate.as<FusedState>(), s);
+    const int grid = magk::fused32_grid(ctx->B, ctx->cap, ctx->t1 - ctx->t0);
+    if (dist) {
+        // the streaming protocol of cg_phase_fused, in fp32: the exchange buffer stays in doubles ([4 x g_all dot
+        // partials | q of the interface nodes]), one in-place all-reduce per iteration
+        ctx->pre = false;
+        const int R = ctx->comm.nranks;
+        int32_t most = 1;
+        for (int r = 0; r < R; ++r)
+            most = std::max(most, (int32_t)(((int64_t)ctx->T * (r + 1)) / R - ((int64_t)ctx->T * r) / R));
+        ctx->g_all = magk::fused32_grid(ctx->B, ctx->cap, most);
+        ctx->cwords = 4 * (size_t)ctx->g_all + 2 * (size_t)ctx->n_iface;
+        HIPCHK(ctx->comm_f.reserve(8 * 2 * ctx->cwords + 64));
+        HIPCHK(ctx->own_qslot.reserve(4 * (size_t)N));
+        HIPCHK(ctx->halo_qslot.reserve(4 * (size_t)std::max<int64_t>(ctx->halo_total, 1)));
+        magk::comm_slots(ctx->iface.as<int32_t>(), ctx->n_iface, ctx->own0, ctx->own1, ctx->halo_g.as<int32_t>(),
+                         ctx->halo_total, N, ctx->own_qslot.as<int32_t>(), ctx->halo_qslot.as<int32_t>(), s);
+        double *c0 = ctx->comm_f.as<double>();
+        HIPCHK(hipMemsetAsync(c0, 0, 8 * 2 * ctx->cwords, s));
+        magk::fused32_init(ctx->bP.as<double2>(), ctx->rqp32a.as<magk::Rqp32>(), ctx->rqp32b.as<magk::Rqp32>(),
+                           ctx->x32.as<float2>(), N, ctx->B, ctx->T, ctx->t0, ctx->t1, c0, ctx->g_all, grid, s);
+        std::string msg;
+        if (int rc = ctx->comm.allreduce_sum(c0, (int64_t)ctx->cwords, s, msg)) return fail(ctx, rc, "%s", msg.c_str());
+        magk::fused_setup(c0, ctx->g_all, ctx->g_all, ctx->opt.stop_mode, ctx->opt.tol, (long long)ctx->opt.max_iter,
+                          ctx->fstate.as<FusedState>(), s);
+    } else {
+        HIPCHK(hipMemsetAsync(ctx->fpart.p, 0, 8 * 2 * 4 * (size_t)stride, s));
+        magk::fused32_init(ctx->bP.as<double2>(), ctx->rqp32a.as<magk::Rqp32>(), ctx->rqp32b.as<magk::Rqp32>(),
+                           ctx->x32.as<float2>(), N, ctx->B, ctx->T, 0, ctx->T, ctx->fpart.as<double>(), stride, grid, s);
+        magk::fused_setup(ctx->fpart.as<double>(), grid, stride, ctx->opt.stop_mode, ctx->opt.tol,
+                          (long long)ctx->opt.max_iter, ctx->fstate.as<FusedState>(), s);
+    }
     HIPCHK(hipGetLastError());
     const int G = ctx->opt.check_every;
     const long long max_blocks = (long long)(ctx->opt.max_iter / G) + 3;
@@ -1327,7 +1353,6 @@ int cg_phase_fused32(mag_ctx *ctx)
             const int par = i & 1;
             P.N = N;
             P.T = ctx->T;
-            P.nPart = grid;
             P.cap = ctx->cap;
             P.par = par;
             P.hist_len = ctx->opt.history_len;
@@ -1343,12 +1368,38 @@ int cg_phase_fused32(mag_ctx *ctx)
             P.in = (par ? ctx->rqp32b : ctx->rqp32a).as<magk::Rqp32>();
             P.out = (par ? ctx->rqp32a : ctx->rqp32b).as<magk::Rqp32>();
             P.x = ctx->x32.as<float2>();
-            P.part_in = ctx->fpart.as<double>() + (size_t)par * 4 * stride;
-            P.part_out = ctx->fpart.as<double>() + (size_t)(par ^ 1) * 4 * stride;
-            P.part_stride = stride;
+            if (dist) {
+                double *cin = ctx->comm_f.as<double>() + (size_t)par * ctx->cwords;
+                double *cout = ctx->comm_f.as<double>() + (size_t)(par ^ 1) * ctx->cwords;
+                P.t0 = ctx->t0;
+                P.t1 = ctx->t1;
+                P.own0 = ctx->own0;
+                P.own1 = ctx->own1;
+                P.n_iface = ctx->n_iface;
+                P.iface = ctx->iface.as<int32_t>();
+                P.own_qslot = ctx->own_qslot.as<int32_t>();
+                P.halo_qslot = ctx->halo_qslot.as<int32_t>();
+                P.part_in = cin;
+                P.part_stride_in = ctx->g_all;
+                P.nPart = ctx->g_all;
+                P.part_out = cout;
+                P.part_stride = ctx->g_all;
+                P.comm_in_q = (const double2 *)(cin + 4 * (size_t)ctx->g_all);
+                P.comm_out_q = (double2 *)(cout + 4 * (size_t)ctx->g_all);
+            } else {
+                P.nPart = grid;
+                P.part_in = ctx->fpart.as<double>() + (size_t)par * 4 * stride;
+                P.part_out = ctx->fpart.as<double>() + (size_t)(par ^ 1) * 4 * stride;
+                P.part_stride = stride;
+            }
             P.st = ctx->fstate.as<FusedState>();
             P.hist = ctx->hist.as<double>();
             magk::fused32_launch(P, ctx->B, grid, s);
+            if (dist) {
+                std::string msg;
+                if (int rc = ctx->comm.allreduce_sum(P.part_out, (int64_t)ctx->cwords, s, msg))
+                    return fail(ctx, rc, "%s", msg.c_str());
+            }
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(&ctx->h_fstate[slot], ctx->fstate.p, sizeof(FusedState), hipMemcpyDeviceToHost, s));
@@ -1359,7 +1410,12 @@ int cg_phase_fused32(mag_ctx *ctx)
         }
         slot ^= 1;
     }
+    if (dist) magk::zero_unowned32(ctx->x32.as<float2>(), N, ctx->own0, ctx->own1, s);
     magk::x32_to_f64(ctx->x32.as<float2>(), N, ctx->x.as<double2>(), s);
+    if (dist) { // every rank returns the whole solution: owned entries summed over ranks
+        std::string msg;
+        if (int rc = ctx->comm.allreduce_sum(ctx->x.as<double>(), 2 * N, s, msg)) return fail(ctx, rc, "%s", msg.c_str());
+    }
     HIPCHK(hipMemcpyAsync(&ctx->h_fstate[2], ctx->fstate.p, sizeof(FusedState), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const FusedState &st = ctx->h_fstate[2];

@@ -1576,7 +1576,7 @@ void comm_slots(const int32_t *iface, int32_t n_iface, int32_t own0, int32_t own
 // stored relative to the reading tile's first node: element-size differences of O(1) coordinates would keep only
 // ~3 digits in fp32, tile-relative ones keep ~6.  Opt-in (mag_options.precision = 1); it cannot meet the 1e-8
 // parity bar and is never the default.
-template <int B>
+template <int B, bool COMM>
 __global__ void __launch_bounds__(B) k_cg_fused32(const Fused32Params P)
 {
     extern __shared__ __attribute__((aligned(16))) double2 smem[];
@@ -1596,16 +1596,21 @@ __global__ void __launch_bounds__(B) k_cg_fused32(const Fused32Params P)
     bool valid = false, hvalid = false;
     float2 ca, ar, aq, ap, xo, hc, hr, hq, hp;
     uint8_t m = 3;
-    int32_t deg = 0, nh = 0, hoff = 0;
+    int32_t deg = 0, nh = 0, hoff = 0, oslot = -1;
     uint32_t w[kSlotRegs];
     const uint32_t *ell = nullptr;
     const float2 z = make_float2(0.f, 0.f);
+    auto iface_q = [&](int32_t slot) { // q of an interface node another rank owns: from the all-reduced exchange buffer
+        const double2 v = P.comm_in_q[slot];
+        return make_float2((float)v.x, (float)v.y);
+    };
     auto load_tile = [&](int32_t t) {
         const TileMeta tm = P.meta[t];
         node = (int64_t)t * B + tid;
         valid = node < P.N;
         ca = ar = aq = ap = xo = z;
         m = 3;
+        oslot = -1;
         if (valid) {
             const Rqp32 rec = P.in[node];
             ar = rec.r;
@@ -1614,6 +1619,7 @@ __global__ void __launch_bounds__(B) k_cg_fused32(const Fused32Params P)
             xo = P.x[node];
             ca = P.xyP32[node];
             m = P.maskP[node];
+            if (COMM) oslot = P.own_qslot[node];
         }
         deg = tm.deg;
         ell = P.ell16 + tm.ell_off + tid;
@@ -1630,14 +1636,20 @@ __global__ void __launch_bounds__(B) k_cg_fused32(const Fused32Params P)
             hr = rec.r;
             hq = rec.q;
             hp = rec.p;
+            if (COMM) {
+                const int32_t hs = P.halo_qslot[hoff + tid];
+                if (hs >= 0) hq = iface_q(hs);
+            }
         }
     };
-    load_tile(blockIdx.x);
+    const int32_t t_first = COMM ? P.t0 : 0, t_end = COMM ? P.t1 : P.T;
+    load_tile(t_first + blockIdx.x);
 
     double S[4] = {0.0, 0.0, 0.0, 0.0};
+    const int32_t stride_in = COMM ? P.part_stride_in : P.part_stride;
     for (int i = tid; i < P.nPart; i += B) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) S[c] += P.part_in[c * P.part_stride + i];
+        for (int c = 0; c < 4; ++c) S[c] += P.part_in[c * stride_in + i];
     }
     block_sum4<B>(S, s_red);
     if (was_done) return;
@@ -1647,7 +1659,7 @@ __global__ void __launch_bounds__(B) k_cg_fused32(const Fused32Params P)
 
     const float c0 = P.c0, nu = P.nu, h = P.h;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    int32_t t = blockIdx.x;
+    int32_t t = t_first + blockIdx.x;
     for (;;) {
         float2 rn, pn;
         rn.x = ar.x + alpha * aq.x;
@@ -1668,6 +1680,10 @@ __global__ void __launch_bounds__(B) k_cg_fused32(const Fused32Params P)
                 r2 = rec.r;
                 q2 = rec.q;
                 p2 = rec.p;
+                if (COMM) {
+                    const int32_t hs = P.halo_qslot[hoff + hh];
+                    if (hs >= 0) q2 = iface_q(hs);
+                }
             }
             float2 hrn, hpn;
             hrn.x = r2.x + alpha * q2.x;
@@ -1698,14 +1714,40 @@ __global__ void __launch_bounds__(B) k_cg_fused32(const Fused32Params P)
             o.p = pn;
             P.out[node] = o;
             P.x[node] = xo;
+            if (COMM && oslot >= 0) P.comm_out_q[oslot] = make_double2((double)fx, (double)fy);
             acc[0] += (double)rn.x * rn.x + (double)rn.y * rn.y;
             acc[1] += (double)pn.x * fx + (double)pn.y * fy;
             acc[2] += (double)rn.x * fx + (double)rn.y * fy;
             acc[3] += (double)fx * fx + (double)fy * fy;
         }
         t += gridDim.x;
-        if (t >= P.T) break;
+        if (t >= t_end) break;
         load_tile(t);
+    }
+    if (COMM) {
+        // as k_cg_fused: records of interface nodes other ranks own are advanced locally, their slot of the outgoing
+        // buffer is this rank's zero; partial slots this (smaller) grid does not fill are zeroed
+        for (int32_t k = blockIdx.x * B + tid; k < P.n_iface; k += gridDim.x * B) {
+            const int32_t g = P.iface[k];
+            if (g < P.own0 || g >= P.own1) {
+                const Rqp32 rec = P.in[g];
+                const float2 qg = iface_q(k);
+                float2 rn, pn;
+                rn.x = rec.r.x + alpha * qg.x;
+                rn.y = rec.r.y + alpha * qg.y;
+                pn.x = -rn.x + beta * rec.p.x;
+                pn.y = -rn.y + beta * rec.p.y;
+                P.out[g].r = rn;
+                P.out[g].p = pn;
+                P.comm_out_q[k] = make_double2(0.0, 0.0);
+            }
+        }
+        if (blockIdx.x == 0) {
+            for (int32_t i = gridDim.x + tid; i < P.part_stride; i += B) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) P.part_out[c * P.part_stride + i] = 0.0;
+            }
+        }
     }
     block_sum4<B>(acc, s_red);
     if (tid == 0) {
@@ -1722,8 +1764,8 @@ int fused32_grid(int32_t B, int32_t cap, int32_t tiles)
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const size_t lds = fused32_lds_bytes(cap, B);
-    hipError_t e = B == 256 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_fused32<256>, 256, lds)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_fused32<512>, 512, lds);
+    hipError_t e = B == 256 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_fused32<256, true>, 256, lds)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_fused32<512, true>, 512, lds);
     if (e != hipSuccess || per_cu < 1) per_cu = 1;
     long g = (long)per_cu * cus;
     if (g > kMaxGrid) g = kMaxGrid;
@@ -1734,10 +1776,16 @@ int fused32_grid(int32_t B, int32_t cap, int32_t tiles)
 void fused32_launch(const Fused32Params &P, int32_t B, int32_t grid, hipStream_t s)
 {
     const size_t lds = fused32_lds_bytes(P.cap, B);
-    if (B == 256)
-        k_cg_fused32<256><<<grid, 256, lds, s>>>(P);
+    const bool comm = P.comm_out_q != nullptr;
+    if (B == 256) {
+        if (comm)
+            k_cg_fused32<256, true><<<grid, 256, lds, s>>>(P);
+        else
+            k_cg_fused32<256, false><<<grid, 256, lds, s>>>(P);
+    } else if (comm)
+        k_cg_fused32<512, true><<<grid, 512, lds, s>>>(P);
     else
-        k_cg_fused32<512><<<grid, 512, lds, s>>>(P);
+        k_cg_fused32<512, false><<<grid, 512, lds, s>>>(P);
 }
 
 __global__ void __launch_bounds__(256) k_coords32(const double2 *xyP, const int32_t *halo_g, const int32_t *tile_hoff,
@@ -1766,7 +1814,7 @@ void coords32(const double *xyP, const int32_t *halo_g, const int32_t *tile_hoff
 
 template <int B>
 __global__ void __launch_bounds__(B) k_fused32_init(const double2 *bP, Rqp32 *in, Rqp32 *out, float2 *x, int64_t N,
-                                                    int32_t T, double *part, int32_t stride)
+                                                    int32_t T, int32_t t0, int32_t t1, double *part, int32_t stride)
 {
     __shared__ double s_red[B / 64];
     double acc = 0.0;
@@ -1782,7 +1830,7 @@ __global__ void __launch_bounds__(B) k_fused32_init(const double2 *bP, Rqp32 *in
             in[node] = rec;
             out[node] = rec;
             x[node] = z;
-            acc += (double)rec.r.x * rec.r.x + (double)rec.r.y * rec.r.y;
+            if (t >= t0 && t < t1) acc += (double)rec.r.x * rec.r.x + (double)rec.r.y * rec.r.y; // this rank's tiles
         }
     }
     const double tot = block_sum<B>(acc, s_red);
@@ -1794,13 +1842,24 @@ __global__ void __launch_bounds__(B) k_fused32_init(const double2 *bP, Rqp32 *in
     }
 }
 
-void fused32_init(const double2 *bP, Rqp32 *in, Rqp32 *out, float2 *x, int64_t N, int32_t B, int32_t T, double *part,
-                  int32_t stride, int32_t grid, hipStream_t s)
+void fused32_init(const double2 *bP, Rqp32 *in, Rqp32 *out, float2 *x, int64_t N, int32_t B, int32_t T, int32_t t0,
+                  int32_t t1, double *part, int32_t stride, int32_t grid, hipStream_t s)
 {
     if (B == 256)
-        k_fused32_init<256><<<grid, 256, 0, s>>>(bP, in, out, x, N, T, part, stride);
+        k_fused32_init<256><<<grid, 256, 0, s>>>(bP, in, out, x, N, T, t0, t1, part, stride);
     else
-        k_fused32_init<512><<<grid, 512, 0, s>>>(bP, in, out, x, N, T, part, stride);
+        k_fused32_init<512><<<grid, 512, 0, s>>>(bP, in, out, x, N, T, t0, t1, part, stride);
+}
+
+__global__ void __launch_bounds__(256) k_zero_unowned32(float2 *x, int64_t N, int64_t own0, int64_t own1)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < N && (i < own0 || i >= own1)) x[i] = make_float2(0.f, 0.f);
+}
+
+void zero_unowned32(float2 *x, int64_t N, int64_t own0, int64_t own1, hipStream_t s)
+{
+    k_zero_unowned32<<<(int)((N + 255) / 256), 256, 0, s>>>(x, N, own0, own1);
 }
 
 __global__ void __launch_bounds__(256) k_x32_to_f64(const float2 *x32, int64_t N, double2 *x)

@@ -337,6 +337,12 @@ struct Rqp32 {
 struct Fused32Params {
     int64_t N;
     int32_t T, nPart, cap, par, hist_len, pad;
+    // multi-GPU (all zero / null on one GPU): tile and node range of this rank, the exchange buffers of the streaming
+    // protocol (k_cg_fused's, with q converted to fp64 on the way: one all-reduce of doubles serves both precisions)
+    int32_t t0, t1, own0, own1, n_iface, part_stride_in;
+    const int32_t *iface, *own_qslot, *halo_qslot;
+    const double2 *comm_in_q;
+    double2 *comm_out_q;
     const float2 *xyP32;     // owned nodes, relative to their tile's first node
     const uint8_t *maskP;
     const TileMeta *meta;
@@ -358,8 +364,9 @@ void coords32(const double *xyP, const int32_t *halo_g, const int32_t *tile_hoff
               float *xyP32, float *halo_xy32, hipStream_t s);
 void fused32_launch(const Fused32Params &P, int32_t B, int32_t grid, hipStream_t s);
 int fused32_grid(int32_t B, int32_t cap, int32_t tiles);
-void fused32_init(const double2 *bP, Rqp32 *in, Rqp32 *out, float2 *x, int64_t N, int32_t B, int32_t T, double *part,
-                  int32_t stride, int32_t grid, hipStream_t s);
+void fused32_init(const double2 *bP, Rqp32 *in, Rqp32 *out, float2 *x, int64_t N, int32_t B, int32_t T, int32_t t0,
+                  int32_t t1, double *part, int32_t stride, int32_t grid, hipStream_t s);
+void zero_unowned32(float2 *x, int64_t N, int64_t own0, int64_t own1, hipStream_t s);
 void x32_to_f64(const float2 *x32, int64_t N, double2 *x, hipStream_t s);
 
 int cg_grid(int32_t T);

@@ -144,6 +144,25 @@ def test_eight_ranks_agree_to_fall_back(case, monkeypatch):
     assert all(outs[0]["persist_timeout"] == 1 for outs in results)
 
 
+def test_eight_ranks_fp32_leg_of_config5(case):
+    """BASELINE config 5 asks for fp64 vs fp32 CG across 8 GPUs: the fp32 leg (mag_options.precision = 1) runs the same
+    streaming protocol -- one all-reduce per iteration of [dot partials | interface q], kept in doubles -- and follows the
+    single-rank fp32 solve iteration for iteration; like it, it stalls at fp32 accuracy (no 1e-8 parity claim)."""
+    p, ref, _ = case
+    opts = dict(precision=1, stop_mode=_lib.MAG_STOP_REL, tol=1e-7, tile_nodes=512)
+    with Context(device=0, **opts) as c:
+        one = c.solve(p)
+    results = run_ranks(p, inboxes=False, **opts)
+    for rank, outs in enumerate(results):
+        out = outs[0]
+        assert out["converged"] == 1 and out["cg_kernel"] == 4, (rank, out["cg_kernel"])
+        assert abs(out["iterations"] - one["iterations"]) <= max(3, one["iterations"] // 100)
+        assert rel(out["u"], one["u"]) <= 2e-5          # two fp32 solves, different summation orders
+        assert 1e-9 < rel(out["u"], ref["u"]) < 5e-4     # fp32 accuracy, as on one GPU
+        assert 0 < out["nnz"] < 0.3 * one["nnz"]
+        assert np.array_equal(out["u"], results[0][0]["u"])
+
+
 def test_full_matrix_is_still_available_on_a_multi_rank_context(case):
     """mag_assemble_csr on a rank of a multi-rank communicator hands out ALL of K (the run itself kept only the rank's
     rows): bit-identical to the oracle's"""
