@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_DIR, "libmagnetite_hip.so")
+# MAG_LIB_PATH: load another build of the same library (A/B of compiler flags or kernel variants in one GPU session)
+SO_PATH = os.environ.get("MAG_LIB_PATH") or os.path.join(_DIR, "libmagnetite_hip.so")
 CSRC = os.path.join(_DIR, "csrc")
 
 MAG_OK, MAG_ERR_BAD_ARGS, MAG_ERR_BC_MISMATCH, MAG_ERR_NOT_CONVERGED = 0, 1, 2, 3

@@ -105,9 +105,12 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
         hq[s] = make_double2(0.0, 0.0);
     }
     bool done = false;
-    __builtin_amdgcn_s_sleep(20); // ~1 us in all: the other workgroups' records are still on their way, and a sweep
-    __builtin_amdgcn_s_sleep(20); // that comes too early costs a full round trip (measured optimum: 0 -> 15.1 us per
-                                  // iteration, 20+20 -> 13.5, 30+30 -> 14.0)
+    // ~0.85 us in all: the other workgroups' records are still on their way, and a sweep that comes too early costs a
+    // full round trip.  Two fixed s_sleep instructions, re-tuned in round 2 on one box (us per iteration at 1M triangles):
+    // 10+10 10.89, 12+12 10.85, 14+14 10.79, 16+8 10.85, 16+16 10.62, 18+14 10.58, 20+20 10.67, 24+24 10.86; one
+    // s_sleep(32) 10.74, one s_sleep(40) 10.79; the same 40 units as a run-time loop of ten s_sleep(4) 10.87.
+    __builtin_amdgcn_s_sleep(18);
+    __builtin_amdgcn_s_sleep(14);
     for (unsigned spins = 0; spins < P.spin_limit; ++spins) {
         bool ok = true;
         if (!have_rec) {

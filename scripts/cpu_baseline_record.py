@@ -9,7 +9,7 @@ Times oracle/magnetite_oracle.c -- the CPU restatement of src/solver.rs -- on th
   3. the OpenMP CG on all cores for configs 2 and 3.
 Nothing here is scaled or sampled: every number is a complete solve.  bench.py reads `config1_dense_s` from the file.
 
-    python scripts/cpu_baseline_record.py            # ~5 minutes, ~7 GB
+    python scripts/cpu_baseline_record.py [out.json]   # ~5 minutes, ~7 GB
 """
 import json
 import os
@@ -81,7 +81,7 @@ def main():
     kw = dict(stop_mode=oracle.STOP_REL, tol=1e-8)
     rec["config3_hole1m"] = {"stop": "relative residual 1e-8 (bench.py)",
                              "sparse_1_thread": phases(c3, 1, **kw), f"sparse_{cores}_threads": phases(c3, cores, **kw)}
-    out = os.path.join(ROOT, "profiles", "r02_cpu_baseline.json")
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r02_cpu_baseline.json")
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps(rec, indent=1))
 
