@@ -253,7 +253,8 @@ int mag_comm_init_callback(mag_ctx *ctx, int32_t nranks, int32_t rank, mag_allre
  * exchange (one record of sums per rank, q of the interface nodes) goes through the window as tagged granules instead
  * of a collective per iteration; the communicator set by mag_comm_init_* is still used to line the launches up, to
  * agree on a fallback and to assemble the solution.  Without a window, or when the mesh does not fit the chips, the
- * streaming kernels + one all-reduce per iteration run.  NULL / 0 removes the window. */
+ * streaming kernels + one all-reduce per iteration run.  NULL / 0 removes the window.  The window needs no preparation:
+ * the extent a solve uses is cleared by rank 0 before the ranks line up, every solve. */
 int mag_comm_set_window(mag_ctx *ctx, void *host_ptr, uint64_t bytes);
 /* The same protocol with the window where it belongs: one INBOX per rank in that rank's device memory, mapped by the
  * other ranks through HIP IPC.  A rank only reads its own inbox (polls stay in local HBM); writers store into the
