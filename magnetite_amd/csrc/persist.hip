@@ -341,7 +341,10 @@ __device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsi
             if (have_g) s_rec[tid] = v;
             ok = have_g;
         }
-        fetch_halo(ok, false);
+        // device inboxes: the interface q of this workgroup's halo sit in LOCAL memory and were stored before their
+        // owners' records were even summed -- they are fetched in the same sweeps as the republished sums, not after them
+        // (a host window is read only once the sums are there: every miss would be a PCIe round trip)
+        fetch_halo(ok, !P.win_shared);
         if (__syncthreads_and(ok ? 1 : 0)) {
             done = true;
             break;
@@ -352,6 +355,7 @@ __device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsi
     if (!done) return fail();
     if (tid < 4) s_S[tid] = ((const double *)s_rec)[tid];
     __syncthreads();
+    if (!P.win_shared) return true;
     return fetch_window_halo() ? true : fail();
 }
 
