@@ -453,6 +453,11 @@ def main():
             if os.path.exists(rec):  # scripts/cpu_baseline_record.py: BASELINE.md section 2 items 1-3, timed once
                 rj = json.load(open(rec))
                 out["cpu_baseline"]["config1_dense_s"] = rj.get("config1_dense_s")
+                c3 = rj.get("config3_hole1m", {}).get("sparse_1_thread")
+                if c3:  # the UNSCALED 1-thread solve of this very workload, timed once on rj["host"]
+                    out["cpu_baseline"]["config3_full_solve_s"] = c3["assembly_and_bc_s"] + c3["cg_s"]
+                    out["cpu_baseline"]["config3_full_solve_elements_per_s"] = c3["elements_per_s"]
+                out["cpu_baseline"]["record_host"] = rj.get("host")
                 out["cpu_baseline"]["record"] = "profiles/r02_cpu_baseline.json"
         else:
             out["cpu_baseline"] = None
