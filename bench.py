@@ -392,6 +392,17 @@ def main():
     ms_op = ctx.time_operator(args.op_reps)   # the streaming CG iteration kernel (one launch per iteration)
     ms_spmv = ctx.time_spmv(args.op_reps)     # the plain matrix-free SpMV y = M K M v
     u, _, _ = ctx.download()
+    # Self-check of the returned solution, independent of how it was produced and gathered: the true residual
+    # f - K u on the unknown DOFs, with K applied matrix-free to the whole mesh by this rank alone, against |b|.  A
+    # converged solve sits at about the stop tolerance; an exchange or gather that went wrong would not.
+    import numpy as np
+    y = ctx.apply_operator(u, masked=False)
+    free = prob.u_known == 0
+    verify = float(np.linalg.norm((prob.f_in - y)[free]) / max(st["rhs_norm"], 1e-300))
+    verify_bar = max(1e-6, 100.0 * args.tol) if args.precision == "fp64" else 1e-3
+    verify_ok = bool(verify <= verify_bar) if st["converged"] else None
+    if use_dist:
+        verify_ok = all_agree(verify_ok is not False)
     comm = ctx.comm_info()
     fallback = bool(st["persist_timeout"])  # the on-chip kernel was chosen, gave up at its grid barrier, streaming redid it
 
@@ -432,6 +443,8 @@ def main():
             "roofline": roofline,
             "spmv": spmv,
             "fallback": fallback,
+            "verify": {"rel_true_residual": verify, "bar": verify_bar, "ok_on_every_rank": verify_ok,
+                       "what": "|f - K u| on the unknown DOFs / |b|, K applied matrix-free to the whole mesh"},
             "cg_iterations": iters, "cg_converged": int(st["converged"]), "cg_final_cost": st["final_cost"],
             "cg_iters_per_sec": iters / (st["ms_cg"] * 1e-3) if st["ms_cg"] > 0 else None,
             # the SURVEY 8(d) figure of the metric's name: bytes an UNFUSED iteration streams / time per iteration.  An
@@ -477,6 +490,10 @@ def main():
             shm.unlink()
     if use_dist:
         dist.destroy_process_group()
+    if verify_ok is False:
+        print(f"bench.py: the returned solution does not satisfy K u = f (relative true residual {verify:.3e})",
+              file=sys.stderr, flush=True)
+        sys.exit(4)
     if fallback:
         # the line above is marked "fallback": true; a run that silently streamed where the on-chip kernel was chosen
         # must not pass for a result of the default configuration

@@ -95,7 +95,7 @@ struct mag_ctx {
     // multi-GPU partition: this rank owns tiles [t0,t1) = nodes [own0,own1) of the Hilbert order
     int32_t t0 = 0, t1 = 0, own0 = 0, own1 = 0, n_iface = 0;
     bool dist = false; // CG runs the distributed protocol (nranks > 1, or forced for a 1-rank rehearsal)
-    DevBuf iface, comm_pq, comm_rr;
+    DevBuf iface, comm_pq, comm_rr, gath_send, gath_recv;
 
     // CSR of K (caller numbering)
     int64_t nb = 0;
@@ -754,6 +754,35 @@ int ensure_graph(mag_ctx *ctx, int G)
     return MAG_OK;
 }
 
+// Every rank returns the whole solution, as solver::run would: the owned node ranges (contiguous in the Hilbert order,
+// equal up to one tile) are all-gathered -- (R-1)/R of the vector per GPU over the ring, half of what summing a
+// zero-padded full vector costs -- and copied to their places.
+int gather_solution(mag_ctx *ctx)
+{
+    const int R = ctx->comm.nranks;
+    if (R <= 1 && !ctx->dist) return MAG_OK;
+    hipStream_t s = ctx->stream;
+    const int64_t N = ctx->N, B = ctx->B, T = ctx->T;
+    auto lo = [&](int r) { return std::min<int64_t>((((int64_t)T * r) / R) * B, N); };
+    int64_t most = 0;
+    for (int r = 0; r < R; ++r) most = std::max(most, lo(r + 1) - lo(r));
+    const size_t cnt = 2 * (size_t)most; // doubles per rank
+    HIPCHK(ctx->gath_send.reserve(8 * cnt + 64));
+    HIPCHK(ctx->gath_recv.reserve(8 * cnt * (size_t)R + 64));
+    const int64_t mine = ctx->own1 - ctx->own0;
+    HIPCHK(hipMemsetAsync(ctx->gath_send.p, 0, 8 * cnt, s));
+    HIPCHK(hipMemcpyAsync(ctx->gath_send.p, ctx->x.as<double>() + 2 * (size_t)ctx->own0, 16 * (size_t)mine,
+                          hipMemcpyDeviceToDevice, s));
+    std::string msg;
+    if (int rc = ctx->comm.allgather(ctx->gath_send.as<double>(), ctx->gath_recv.as<double>(), (int64_t)cnt, s, msg))
+        return fail(ctx, rc, "%s", msg.c_str());
+    for (int r = 0; r < R; ++r)
+        if (lo(r + 1) > lo(r))
+            HIPCHK(hipMemcpyAsync(ctx->x.as<double>() + 2 * (size_t)lo(r), ctx->gath_recv.as<double>() + cnt * (size_t)r,
+                                  16 * (size_t)(lo(r + 1) - lo(r)), hipMemcpyDeviceToDevice, s));
+    return MAG_OK;
+}
+
 // solver.rs:139-176 on the device: blocks of G iterations; the host polls the device-side state one
 // block behind the one it has just queued, so the GPU never waits for the host.
 int cg_phase(mag_ctx *ctx)
@@ -801,13 +830,8 @@ int cg_phase(mag_ctx *ctx)
         }
         slot ^= 1;
     }
-    if (ctx->dist) {
-        // assemble the full solution on every rank: each contributes its own nodes, zeros elsewhere
-        magk::zero_unowned(ctx->x.as<double2>(), ctx->N, ctx->own0, ctx->own1, s);
-        std::string msg;
-        if (int rc = ctx->comm.allreduce_sum(ctx->x.as<double>(), 2 * ctx->N, s, msg))
-            return fail(ctx, rc, "%s", msg.c_str());
-    }
+    if (ctx->dist)
+        if (int rc = gather_solution(ctx)) return rc;
     HIPCHK(hipMemcpyAsync(&ctx->h_state[2], ctx->state.p, sizeof(CgState), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const CgState &st = ctx->h_state[2];
@@ -1021,12 +1045,8 @@ int cg_phase_fused(mag_ctx *ctx)
         }
         slot ^= 1;
     }
-    if (ctx->dist) {
-        magk::zero_unowned(ctx->x.as<double2>(), ctx->N, ctx->own0, ctx->own1, s);
-        std::string msg;
-        if (int rc = ctx->comm.allreduce_sum(ctx->x.as<double>(), 2 * ctx->N, s, msg))
-            return fail(ctx, rc, "%s", msg.c_str());
-    }
+    if (ctx->dist)
+        if (int rc = gather_solution(ctx)) return rc;
     HIPCHK(hipMemcpyAsync(&ctx->h_fstate[2], ctx->fstate.p, sizeof(FusedState), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const FusedState &st = ctx->h_fstate[2];
@@ -1167,11 +1187,8 @@ int cg_phase_persist(mag_ctx *ctx)
         return cg_phase_fused(ctx);
     }
     ctx->cg_kernel = 2;
-    if (mg) { // every rank returns the whole solution: owned entries summed over ranks, as on the streaming path
-        magk::zero_unowned(ctx->x.as<double2>(), ctx->N, ctx->own0, ctx->own1, s);
-        std::string msg;
-        if (int rc = ctx->comm.allreduce_sum(ctx->x.as<double>(), 2 * ctx->N, s, msg))
-            return fail(ctx, rc, "%s", msg.c_str());
+    if (mg) { // every rank returns the whole solution
+        if (int rc = gather_solution(ctx)) return rc;
         HIPCHK(hipStreamSynchronize(s));
     }
     ctx->stats.iterations = st.iterations;
@@ -1410,12 +1427,9 @@ int cg_phase_fused32(mag_ctx *ctx)
         }
         slot ^= 1;
     }
-    if (dist) magk::zero_unowned32(ctx->x32.as<float2>(), N, ctx->own0, ctx->own1, s);
     magk::x32_to_f64(ctx->x32.as<float2>(), N, ctx->x.as<double2>(), s);
-    if (dist) { // every rank returns the whole solution: owned entries summed over ranks
-        std::string msg;
-        if (int rc = ctx->comm.allreduce_sum(ctx->x.as<double>(), 2 * N, s, msg)) return fail(ctx, rc, "%s", msg.c_str());
-    }
+    if (dist)
+        if (int rc = gather_solution(ctx)) return rc;
     HIPCHK(hipMemcpyAsync(&ctx->h_fstate[2], ctx->fstate.p, sizeof(FusedState), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const FusedState &st = ctx->h_fstate[2];

@@ -671,18 +671,6 @@ void iface_unpack(const double *buf, const int32_t *iface, int32_t n_iface, int3
     k_iface_unpack<<<grid, 256, 0, s>>>(buf, iface, n_iface, own0, own1, v);
 }
 
-// x of the other ranks' nodes is zeroed so that a sum all-reduce assembles the full solution
-__global__ void __launch_bounds__(256) k_zero_unowned(double2 *x, int64_t N, int64_t own0, int64_t own1)
-{
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < N && (i < own0 || i >= own1)) x[i] = make_double2(0.0, 0.0);
-}
-
-void zero_unowned(double2 *x, int64_t N, int64_t own0, int64_t own1, hipStream_t s)
-{
-    k_zero_unowned<<<(int)((N + 255) / 256), 256, 0, s>>>(x, N, own0, own1);
-}
-
 __global__ void __launch_bounds__(256) k_cg_setup(const double *partRR, int nPart, int stop_mode, double tol,
                                                   long long max_iter, CgState *st)
 {
@@ -1849,17 +1837,6 @@ void fused32_init(const double2 *bP, Rqp32 *in, Rqp32 *out, float2 *x, int64_t N
         k_fused32_init<256><<<grid, 256, 0, s>>>(bP, in, out, x, N, T, t0, t1, part, stride);
     else
         k_fused32_init<512><<<grid, 512, 0, s>>>(bP, in, out, x, N, T, t0, t1, part, stride);
-}
-
-__global__ void __launch_bounds__(256) k_zero_unowned32(float2 *x, int64_t N, int64_t own0, int64_t own1)
-{
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < N && (i < own0 || i >= own1)) x[i] = make_float2(0.f, 0.f);
-}
-
-void zero_unowned32(float2 *x, int64_t N, int64_t own0, int64_t own1, hipStream_t s)
-{
-    k_zero_unowned32<<<(int)((N + 255) / 256), 256, 0, s>>>(x, N, own0, own1);
 }
 
 __global__ void __launch_bounds__(256) k_x32_to_f64(const float2 *x32, int64_t N, double2 *x)

@@ -17,6 +17,7 @@ struct Rccl {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -40,10 +41,11 @@ Rccl &rccl()
         r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.handle, "ncclGetUniqueId");
         r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.handle, "ncclCommInitRank");
         r.AllReduce = (decltype(r.AllReduce))dlsym(r.handle, "ncclAllReduce");
+        r.AllGather = (decltype(r.AllGather))dlsym(r.handle, "ncclAllGather");
         r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.handle, "ncclCommDestroy");
         r.CommCount = (decltype(r.CommCount))dlsym(r.handle, "ncclCommCount");
         r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.handle, "ncclGetErrorString");
-        if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy || !r.GetErrorString)
+        if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.AllGather || !r.CommDestroy || !r.GetErrorString)
             r.err = "librccl is missing a required symbol";
     });
     return r;
@@ -147,6 +149,28 @@ int Comm::allreduce_sum(double *dev_buf, int64_t count, hipStream_t s, std::stri
         return MAG_ERR_STATE;
     }
     return MAG_OK;
+}
+
+int Comm::allgather(const double *dev_send, double *dev_recv, int64_t count, hipStream_t s, std::string &msg)
+{
+    if (count <= 0) return MAG_OK;
+    if (nccl) {
+        Rccl &r = rccl();
+        const ncclResult_t rc = r.AllGather(dev_send, dev_recv, (size_t)count, ncclDouble, (ncclComm_t)nccl, s);
+        if (rc != ncclSuccess) {
+            msg = std::string("ncclAllGather failed: ") + r.GetErrorString(rc);
+            return MAG_ERR_RCCL;
+        }
+        return MAG_OK;
+    }
+    // callback transport / no transport: own segment into a zeroed buffer, summed over ranks
+    if (hipMemsetAsync(dev_recv, 0, 8 * (size_t)count * (size_t)nranks, s) != hipSuccess ||
+        hipMemcpyAsync(dev_recv + (size_t)rank * (size_t)count, dev_send, 8 * (size_t)count, hipMemcpyDeviceToDevice, s) !=
+            hipSuccess) {
+        msg = "staging of the all-gather buffer failed";
+        return MAG_ERR_HIP;
+    }
+    return allreduce_sum(dev_recv, count * nranks, s, msg);
 }
 
 int Comm::rccl_count() const

@@ -28,6 +28,9 @@ struct Comm {
     int init_callback(int nranks_, int rank_, mag_allreduce_fn fn, void *user, std::string &msg);
     // in-place sum over ranks of count doubles at dev_buf, ordered on stream s
     int allreduce_sum(double *dev_buf, int64_t count, hipStream_t s, std::string &msg);
+    // every rank contributes `count` doubles at dev_send; dev_recv receives nranks * count doubles in rank order
+    // (RCCL: ncclAllGather; callback transport: placed into a zeroed buffer and sum-all-reduced -- same result)
+    int allgather(const double *dev_send, double *dev_recv, int64_t count, hipStream_t s, std::string &msg);
     // true when allreduce_sum only enqueues work on s (RCCL); false when it synchronises (callback)
     bool stream_ordered() const { return nccl != nullptr; }
     // ranks of the RCCL communicator as RCCL itself reports them (ncclCommCount); 0 without one, -1 on error

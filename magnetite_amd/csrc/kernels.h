@@ -366,7 +366,6 @@ void fused32_launch(const Fused32Params &P, int32_t B, int32_t grid, hipStream_t
 int fused32_grid(int32_t B, int32_t cap, int32_t tiles);
 void fused32_init(const double2 *bP, Rqp32 *in, Rqp32 *out, float2 *x, int64_t N, int32_t B, int32_t T, int32_t t0,
                   int32_t t1, double *part, int32_t stride, int32_t grid, hipStream_t s);
-void zero_unowned32(float2 *x, int64_t N, int64_t own0, int64_t own1, hipStream_t s);
 void x32_to_f64(const float2 *x32, int64_t N, double2 *x, hipStream_t s);
 
 int cg_grid(int32_t T);
@@ -381,7 +380,6 @@ void iface_pack(const double *part, int nPart, const double2 *v, const int32_t *
                 int32_t own1, double *buf, hipStream_t s);
 void iface_unpack(const double *buf, const int32_t *iface, int32_t n_iface, int32_t own0, int32_t own1, double2 *v,
                   hipStream_t s);
-void zero_unowned(double2 *x, int64_t N, int64_t own0, int64_t own1, hipStream_t s);
 // one block: bb = sum(partRR), thresholds, counters
 void cg_setup(const double *partRR, int32_t nPart, int stop_mode, double tol, long long max_iter, CgState *st,
               hipStream_t s);

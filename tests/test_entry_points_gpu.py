@@ -24,6 +24,8 @@ def check_roofline(d):
             assert 0.0 < rf["counted"]["valu_busy"] <= 1.0 and 0.0 < rf["counted"]["hbm_frac_live"] <= 1.0
     else:
         assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    # the line vouches for its own solution: true residual |f - K u| / |b| at about the stop tolerance, on every rank
+    assert d["verify"]["ok_on_every_rank"] is True and 0.0 < d["verify"]["rel_true_residual"] <= d["verify"]["bar"]
     sp = d["spmv"]
     assert sp["bound"] == "hbm" and 0.0 < sp["frac"] <= 1.0 and abs(sp["frac"] - sp["achieved"] / sp["peak"]) < 1e-12
 
@@ -88,7 +90,7 @@ def test_bench_multi_rank_code_path_on_one_gpu(built, window):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None and "rehearsal" in d
     assert d["config"]["parallelism"] == "hilbert-tile-ranges2" and d["config"]["ranks"] == 2 and d["config"]["elements"] == 2 * 100352
-    assert d["cg_converged"] == 1 and d["value"] > 0
+    assert d["cg_converged"] == 1 and d["value"] > 0 and d["verify"]["ok_on_every_rank"] is True
     if window == "host-window":  # two ranks x ~50 workgroups fit the one GPU side by side: the on-chip CG runs
         assert d["config"]["cg_kernel"] == 2 and "window" in d["config"]["exchange"]
     elif window == "allreduce":  # streaming kernels, one all-reduce per iteration
