@@ -486,6 +486,40 @@ int csr_symbolic(mag_ctx *ctx)
         HIPCHK(hipStreamSynchronize(s));
         magk::mark_local(ctx->perm.as<uint32_t>(), ctx->maskP.as<uint8_t>(), N, ctx->own0, ctx->own1,
                          ctx->halo_g.as<int32_t>(), h2[0], h2[1], ctx->local_node.as<uint8_t>(), s);
+    }
+    HIPCHK(ctx->rowcnt.reserve(4 * ((size_t)N + 1)));
+    HIPCHK(ctx->bptr.reserve(4 * ((size_t)N + 1)));
+    // Default: the pattern straight from the incidence lists (k_pattern_rows: no pair list, no 9E-key sort -- 0.15 ms
+    // instead of 0.9 ms at 1M triangles).  The sort-based pattern below serves rows too long for its register array
+    // (valence >= 16) and the A/B assembly modes that walk the sorted pair list.
+    const char *how = getenv("MAG_TUNE_ASSEMBLY");
+    const bool want_pairs = getenv("MAG_TUNE_KE_BUFFER") || (how && !strcmp(how, "rows")) || getenv("MAG_TUNE_PATTERN_SORT");
+    if (!want_pairs) {
+        int32_t *ovf = (int32_t *)(ctx->small.as<double>() + 4 * 256 + 4) + 2;
+        const uint8_t *local = shard ? ctx->local_node.as<uint8_t>() : nullptr;
+        HIPCHK(hipMemsetAsync(ovf, 0, 4, s));
+        magk::pattern_count(ctx->inc_off.as<int32_t>(), ctx->inc.as<uint32_t>(), ctx->perm.as<uint32_t>(),
+                            ctx->conn.as<int32_t>(), local, N, ctx->rowcnt.as<int32_t>(), ovf, s);
+        if (int rc = scan_i32(ctx, ctx->rowcnt.as<int32_t>(), ctx->bptr.as<int32_t>(), (size_t)N + 1)) return rc;
+        int32_t h_nb = 0, h_ovf = 0;
+        HIPCHK(hipMemcpyAsync(&h_nb, ctx->bptr.as<int32_t>() + N, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(&h_ovf, ovf, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (!h_ovf) {
+            const int64_t nb = h_nb;
+            if (nb <= 0) return fail(ctx, MAG_ERR_STATE, "rank %d keeps no row of K", ctx->comm.rank);
+            if (4 * nb >= (int64_t(1) << 31))
+                return fail(ctx, MAG_ERR_TOO_LARGE, "nnz of K (%lld) exceeds int32", (long long)(4 * nb));
+            ctx->nb = nb;
+            HIPCHK(ctx->bcol.reserve(4 * (size_t)nb));
+            HIPCHK(ctx->kval.reserve(8 * 4 * (size_t)nb));
+            magk::pattern_fill(ctx->inc_off.as<int32_t>(), ctx->inc.as<uint32_t>(), ctx->perm.as<uint32_t>(),
+                               ctx->conn.as<int32_t>(), local, N, ctx->bptr.as<int32_t>(), ctx->bcol.as<int32_t>(), s);
+            HIPCHK(hipGetLastError());
+            return MAG_OK;
+        }
+    }
+    if (shard) {
         magk::csr_pair_count(ctx->conn.as<int32_t>(), E, ctx->local_node.as<uint8_t>(), ctx->ecnt.as<int32_t>(), s);
         if (int rc = scan_i32(ctx, ctx->ecnt.as<int32_t>(), ctx->eoff.as<int32_t>(), (size_t)E + 1)) return rc;
         int32_t h_n = 0;

@@ -50,6 +50,13 @@ void fill_ell16(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn
 void halo_coords(const int32_t *halo_g, const double *xyP, int64_t n, double *halo_xy, hipStream_t s);
 // CSR pattern: 9 (row node, col node) pairs per element, key = row<<32 | col, val = 9e + 3a + b
 void csr_pairs(const int32_t *conn, int64_t E, uint64_t *keys, uint32_t *vals, hipStream_t s);
+// CSR pattern straight from the incidence lists: rowcnt[i] = distinct nodes of node i's incident elements (0 where
+// local is given and local[i] == 0; rowcnt[N] = 0), *overflow = 1 if a row exceeds the register array; then, with
+// bptr = scan(rowcnt), bcol[bptr[i] ..] = those nodes, ascending
+void pattern_count(const int32_t *inc_off, const uint32_t *inc, const uint32_t *perm, const int32_t *conn,
+                   const uint8_t *local, int64_t N, int32_t *rowcnt, int32_t *overflow, hipStream_t s);
+void pattern_fill(const int32_t *inc_off, const uint32_t *inc, const uint32_t *perm, const int32_t *conn,
+                  const uint8_t *local, int64_t N, const int32_t *bptr, int32_t *bcol, hipStream_t s);
 // multi-GPU: local[i] = 1 for the nodes whose K rows this rank keeps (owned, one ghost layer, prescribed nodes) ...
 void mark_local(const uint32_t *perm, const uint8_t *maskP, int64_t N, int32_t own0, int32_t own1,
                 const int32_t *halo_g, int32_t h0, int32_t h1, uint8_t *local, hipStream_t s);

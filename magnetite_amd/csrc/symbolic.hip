@@ -470,6 +470,96 @@ void csr_pairs(const int32_t *conn, int64_t E, uint64_t *keys, uint32_t *vals, h
     k_csr_pairs<<<blocks_for(9 * E, 256), 256, 0, s>>>(conn, 9 * E, keys, vals);
 }
 
+// ---- CSR pattern straight from the incidence lists (default): no pair list, no 9E-key sort ----
+// Row node i's block columns are the distinct nodes of its incident elements (solver.rs:304-322: every (node, node) pair
+// of an element gets an entry, zero or not), ascending.  One thread per node of the Hilbert order walks the node's
+// incidence entries (already sorted and contiguous: the list the operator tables and the assembly use), gathers the
+// elements' node triples four at a time and keeps the distinct ids in a sorted register array of kRowCap slots
+// (insertion by compare-and-select: no run-time indexing).  Pass COUNT writes the row's block count (0 for a row this
+// rank does not keep), a scan gives bptr, pass FILL writes bcol.  A row with more than kRowCap distinct columns
+// (valence >= kRowCap: hub nodes) raises `overflow` and the host falls back to the sort-based pattern (k_csr_pairs ...).
+constexpr int kRowCap = 16;
+
+template <bool FILL>
+__global__ void __launch_bounds__(256) k_pattern_rows(const int32_t *inc_off, const uint32_t *inc, const uint32_t *perm,
+                                                      const int32_t *conn, const uint8_t *local, int64_t N,
+                                                      const int32_t *bptr, int32_t *out, int32_t *overflow)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g > N) return;
+    if (g == N) {
+        if (!FILL) out[N] = 0; // sentinel for the exclusive scan
+        return;
+    }
+    const int64_t i = perm[g];
+    if (local && !local[i]) {
+        if (!FILL) out[i] = 0;
+        return;
+    }
+    int32_t cols[kRowCap];
+#pragma unroll
+    for (int k = 0; k < kRowCap; ++k) cols[k] = 0x7fffffff;
+    int n = 0;
+    bool over = false;
+    auto insert = [&](int32_t v) {
+        int p = 0;
+        bool dup = false;
+#pragma unroll
+        for (int k = 0; k < kRowCap; ++k) {
+            p += cols[k] < v ? 1 : 0;
+            dup |= cols[k] == v;
+        }
+        if (dup) return;
+        if (n == kRowCap) {
+            over = true;
+            return;
+        }
+#pragma unroll
+        for (int k = kRowCap - 1; k > 0; --k) cols[k] = k > p ? cols[k - 1] : (k == p ? v : cols[k]);
+        cols[0] = p == 0 ? v : cols[0];
+        ++n;
+    };
+    const int32_t q1 = inc_off[g + 1];
+    for (int32_t q = inc_off[g]; q < q1; q += 4) {
+        uint32_t v[4];
+        int3 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = q + u < q1 ? inc[q + u] : 0xffffffffu;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (v[u] != 0xffffffffu) t[u] = ((const int3 *)conn)[v[u] / 3u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (v[u] != 0xffffffffu) {
+                insert(t[u].x);
+                insert(t[u].y);
+                insert(t[u].z);
+            }
+    }
+    if (FILL) {
+        const int32_t p = bptr[i];
+#pragma unroll
+        for (int k = 0; k < kRowCap; ++k)
+            if (k < n) out[p + k] = cols[k];
+    } else {
+        out[i] = over ? 0 : n;
+        if (over) *overflow = 1;
+    }
+}
+
+void pattern_count(const int32_t *inc_off, const uint32_t *inc, const uint32_t *perm, const int32_t *conn,
+                   const uint8_t *local, int64_t N, int32_t *rowcnt, int32_t *overflow, hipStream_t s)
+{
+    k_pattern_rows<false><<<blocks_for(N + 1, 256), 256, 0, s>>>(inc_off, inc, perm, conn, local, N, nullptr, rowcnt,
+                                                                overflow);
+}
+
+void pattern_fill(const int32_t *inc_off, const uint32_t *inc, const uint32_t *perm, const int32_t *conn,
+                  const uint8_t *local, int64_t N, const int32_t *bptr, int32_t *bcol, hipStream_t s)
+{
+    k_pattern_rows<true><<<blocks_for(N + 1, 256), 256, 0, s>>>(inc_off, inc, perm, conn, local, N, bptr, bcol, nullptr);
+}
+
 // ---- multi-GPU: the pattern of the rows a rank keeps (owned nodes, one ghost layer, prescribed nodes) ----
 // local[i] (caller numbering) = 1 for: nodes of the rank's own Hilbert range, halo nodes of its tiles (their rows give
 // the right-hand side of the ghost recurrences), and every node with a prescribed displacement (their rows give the
