@@ -412,6 +412,8 @@ def main():
         Eloc, Nloc = E / world, N / world  # per-GPU share: what one launch of the kernels processes
         kind = int(st["cg_kernel"])  # what ran: 2 on-chip single launch, 1 one fused launch per iteration, 0 two launches
         tile_key = f"{args.workload}:tile{args.tile}"
+        if world > 1:  # the committed PMC passes are single-GPU runs of the single-GPU kernels: no counters for N > 1
+            tile_key = "none"
         if kind == 2:
             roofline = roofline_onchip(Eloc, Nloc, iters, st["ms_cg"], load_pmc(f"{tile_key}:kernel2"), args.tile)
         elif kind == 4:  # fp32 leg: value terms halved (r, q, p, x in and out 64N, coordinates 8N, mask 1N); no timing
