@@ -335,6 +335,40 @@ def test_high_valence_fan_mesh(built):
         assert rel(out["u"], ref["u"]) <= TOL_U
 
 
+@pytest.mark.parametrize("valence", [6, 7, 8, 9, 14, 15, 16, 17])
+def test_assembly_fast_paths_at_their_row_length_limits(built, valence, monkeypatch):
+    """A hub of `valence` triangles has valence + 1 blocks in its K row.  The assembly keeps rows of up to 8 blocks in LDS
+    accumulators (longer ones are finished by the whole workgroup), the pattern kernel keeps up to 16 distinct columns in
+    registers (longer rows send the whole pattern to the sort-based construction): K, K_ff and b must be bit-identical to
+    the oracle's on both sides of both limits, and identical between the two pattern constructions."""
+    n = valence
+    ang = np.linspace(0, 2 * np.pi, n, endpoint=False) + 0.1
+    xy = np.concatenate([[[0.0, 0.0]], np.stack([np.cos(ang), np.sin(ang)], axis=1),
+                         2.0 * np.stack([np.cos(ang + np.pi / n), np.sin(ang + np.pi / n)], axis=1)])
+    tri = [[0, 1 + k, 1 + (k + 1) % n] for k in range(n)]
+    tri += [[1 + k, 1 + n + k, 1 + (k + 1) % n] for k in range(n)]
+    m = meshgen.shuffle(meshgen.Mesh(xy, np.array(tri, dtype=np.int32), f"hub{n}"), 5)
+    p = meshgen.apply_boundary_rules(m, [meshgen.BoundaryRule("hold", x_max=-1.5, ux=0.0, uy=0.0),
+                                         meshgen.BoundaryRule("pull", x_min=1.5, ux=0.01, fy=0.0)])
+    K = oracle.assemble_sparse(p.xy_flat, p.conn_flat, p.poisson_ratio, p.youngs_modulus, p.part_thickness)
+    A, bo = oracle.reduce_system(K, p.u_known, p.u_in, p.f_in)
+    assert np.diff(K.rowptr).max() == 2 * (valence + 1)
+    got = {}
+    for how in ("incidence", "sort"):
+        if how == "sort":
+            monkeypatch.setenv("MAG_TUNE_PATTERN_SORT", "1")
+        with Context(device=0) as c:
+            c.upload_problem(p)
+            rowptr, col, val = c.assemble_csr()
+            rp, cf, vf, b = c.reduce_system()
+        assert np.array_equal(rowptr.astype(np.int64), K.rowptr) and np.array_equal(col, K.col), how
+        assert np.array_equal(val, K.val), how
+        assert np.array_equal(rp.astype(np.int64), A.rowptr) and np.array_equal(cf, A.col) and np.array_equal(vf, A.val)
+        assert np.array_equal(b, bo)
+        got[how] = val
+    assert np.array_equal(got["incidence"], got["sort"])
+
+
 @pytest.mark.parametrize("which,scale", [("hole1m", 1.0), ("plate100k", 1.0), ("plate4m", 1.0)])
 def test_full_size_properties(built, which, scale):
     """BASELINE-size meshes, where the oracle does not finish in seconds: size-independent properties.
