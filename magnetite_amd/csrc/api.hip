@@ -471,14 +471,12 @@ int csr_symbolic(mag_ctx *ctx)
     hipStream_t s = ctx->stream;
     // Several ranks: each keeps the rows of its own nodes, of its tiles' halo nodes (one ghost layer: the ghost
     // recurrences need their right-hand side) and of the prescribed nodes (reactions on every rank, no second
-    // collective): solver.rs:304-322 couples rows only through shared elements, so those rows are complete.  The
-    // pairs are filtered BEFORE the sort, so the pattern sort, K and every pass over it shrink with the rank count.
+    // collective): solver.rs:304-322 couples rows only through shared elements, so those rows are complete.  Rows a
+    // rank does not keep get no blocks, so the pattern, K and every pass over them shrink with the rank count.
     const bool shard = ctx->comm.nranks > 1 && !ctx->want_full_csr;
     ctx->csr_full = !shard;
     if (shard) {
         HIPCHK(ctx->local_node.reserve((size_t)N + 64));
-        HIPCHK(ctx->ecnt.reserve(4 * ((size_t)E + 1)));
-        HIPCHK(ctx->eoff.reserve(4 * ((size_t)E + 1)));
         HIPCHK(hipMemsetAsync(ctx->local_node.p, 0, (size_t)N, s));
         std::vector<int32_t> h2(2);
         HIPCHK(hipMemcpyAsync(&h2[0], ctx->tile_hoff.as<int32_t>() + ctx->t0, 4, hipMemcpyDeviceToHost, s));
@@ -520,6 +518,8 @@ int csr_symbolic(mag_ctx *ctx)
         }
     }
     if (shard) {
+        HIPCHK(ctx->ecnt.reserve(4 * ((size_t)E + 1)));
+        HIPCHK(ctx->eoff.reserve(4 * ((size_t)E + 1)));
         magk::csr_pair_count(ctx->conn.as<int32_t>(), E, ctx->local_node.as<uint8_t>(), ctx->ecnt.as<int32_t>(), s);
         if (int rc = scan_i32(ctx, ctx->ecnt.as<int32_t>(), ctx->eoff.as<int32_t>(), (size_t)E + 1)) return rc;
         int32_t h_n = 0;
