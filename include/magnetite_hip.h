@@ -261,7 +261,9 @@ int mag_comm_set_window(mag_ctx *ctx, void *host_ptr, uint64_t bytes);
  * inboxes of the ranks that read a value (across xGMI).  Every rank: mag_comm_inbox_create(ctx, bytes, handle) (bytes
  * as for the window; `handle` receives MAG_IPC_HANDLE_BYTES bytes), exchange the handles by any means, then
  * mag_comm_inbox_open(ctx, all_handles) with the nranks handles in rank order.  bytes = 0 removes the inboxes.
- * Exercised with several ranks on ONE GPU only (12 us per CG iteration with 2 ranks against ~40-90 through host
+ * Each rank's launch ends with one exchange workgroup (no tile: it gathers the rank's partial sums, trades them with the
+ * other ranks through the inboxes and republishes the total) whenever a CU is free for it.
+ * Exercised with up to eight ranks on ONE GPU only (~10 us per CG iteration with 8 ranks against ~40-90 through host
  * memory): measure before relying on it on a node, as bench.py does. */
 #define MAG_IPC_HANDLE_BYTES 64
 int mag_comm_inbox_create(mag_ctx *ctx, uint64_t bytes, void *handle_out);

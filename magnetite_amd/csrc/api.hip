@@ -1140,6 +1140,14 @@ int cg_phase_persist(mag_ctx *ctx)
             P.inbox[r] = (uint8_t *)(ctx->inbox_ready ? ctx->inbox_peer[r] : ctx->win_dev);
         P.iface_readers = ctx->iface_readers.as<uint8_t>();
         P.grec = ctx->grec.as<unsigned long long>();
+        // device inboxes: one extra workgroup carries the rank-level exchange (persist_comm_loop) when a CU is free for
+        // it on every rank -- the grids differ by at most one workgroup, so the largest decides for all
+        int cus = 0;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        const int32_t tiles_max = (ctx->T + R - 1) / R;
+        const int32_t grid_max = (tiles_max + ctx->persist_k - 1) / ctx->persist_k;
+        const char *cw = getenv("MAG_TUNE_COMM_WG");
+        P.comm_wg = (ctx->inbox_ready && grid_max + 1 <= cus && (!cw || atoi(cw) != 0)) ? 1 : 0;
     }
     P.N = ctx->N;
     P.T = ctx->T;
@@ -1187,7 +1195,7 @@ int cg_phase_persist(mag_ctx *ctx)
         HIPCHK(hipMemsetAsync(ctx->comm_pq.p, 0, 8, s));
         if (int rc = ctx->comm.allreduce_sum(ctx->comm_pq.as<double>(), 1, s, msg)) return fail(ctx, rc, "%s", msg.c_str());
     }
-    magk::persist_launch(P, ctx->B, grid, s);
+    magk::persist_launch(P, ctx->B, grid + P.comm_wg, s);
     HIPCHK(hipGetLastError());
     uint32_t h_sync[16] = {};
     HIPCHK(hipMemcpyAsync(&ctx->h_fstate[2], ctx->fstate.p, sizeof(FusedState), hipMemcpyDeviceToHost, s));

@@ -328,6 +328,7 @@ struct PersistParams {
     // stay in local HBM).
     uint8_t *inbox[8];
     int32_t win_shared;
+    int32_t comm_wg; // 1: the grid ends with an exchange workgroup (persist_comm_loop); device inboxes only
     const uint8_t *iface_readers; // n_iface: bit r set when rank r reads the interface node of that slot
     unsigned long long *grec;    // device: 2 * 8 granules, the grid-wide sums republished by workgroup 0
 };

@@ -208,7 +208,7 @@ __device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsi
                                            double2 (&hq)[NH], double *s_S, double2 *s_rec)
 {
     const int tid = threadIdx.x;
-    const int grid = gridDim.x, R = P.nranks;
+    const int grid = (int)gridDim.x - P.comm_wg, R = P.nranks; // compute workgroups
     gu32 *tmo = (gu32 *)P.sync + 9;
     uint8_t *mine = P.inbox[P.rank]; // this rank's inbox: the only one it reads
     gu32 *wtmo = (gu32 *)mine;
@@ -217,7 +217,7 @@ __device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsi
     const unsigned long long *qbase = P.qg + 4 * (int64_t)par * P.N;
     const unsigned long long *wq =
         (const unsigned long long *)(mine + 64 + 128 * (size_t)R) + 4 * (int64_t)par * P.n_iface;
-    const bool lead = blockIdx.x == 0;
+    const bool lead = blockIdx.x == 0 && !P.comm_wg; // with an exchange workgroup nobody leads: all wait for its record
     bool have_h[NH];
 #pragma unroll
     for (int e = 0; e < NH; ++e) {
@@ -359,6 +359,114 @@ __device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsi
     return fetch_window_halo() ? true : fail();
 }
 
+// The EXCHANGE WORKGROUP of the multi-GPU kernel (device inboxes only; PersistParams::comm_wg): one extra workgroup that
+// holds no tile and does nothing but the rank-level exchange workgroup 0 would otherwise carry on top of its four
+// tiles.  It has nothing else to do, so it polls without the initial wait: per epoch it (1) gathers this rank's partial
+// records as they land, (2) sums them in the fixed order and stores the rank's sum into every rank's inbox, (3) gathers
+// every rank's sum from its own inbox, (4) adds them in rank order and republishes the result for this GPU's compute
+// workgroups -- and takes the same stop decision from the same bits, so it leaves when they do.
+__device__ inline void persist_comm_loop(const PersistParams &P, double *s_S, double2 *s_rec)
+{
+    const int tid = threadIdx.x;
+    const int grid = (int)gridDim.x - 1, R = P.nranks;
+    gu32 *tmo = (gu32 *)P.sync + 9;
+    uint8_t *mine = P.inbox[P.rank];
+    gu32 *wtmo = (gu32 *)mine;
+    auto inbox_rec = [&](int r) { return (unsigned long long *)(P.inbox[r] + 64); };
+    auto gave_up = [&](unsigned spins) {
+        if ((spins & 255u) != 255u) return false;
+        const int dead = tid == 0 && (__hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                                      __hip_atomic_load(wtmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u)
+                             ? 1 : 0;
+        return __syncthreads_or(dead) != 0;
+    };
+    auto fail = [&]() {
+        if (tid == 0) __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < R) __hip_atomic_store((gu32 *)P.inbox[tid], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
+    int par = 0;
+    unsigned tag = P.tag_base + 1u;
+    double target = P.tol, bb = 0.0;
+    for (long long j = 0;; ++j) {
+        const unsigned long long *recb = P.recg + 8 * (int64_t)par * grid;
+        // (1) this rank's records
+        bool have_rec = tid >= 2 * grid, done = false;
+        unsigned spins = 0;
+        for (; spins < P.spin_limit; ++spins) {
+            if (!have_rec) {
+                double2 v;
+                have_rec = get_granules(recb, 64u * (uint32_t)grid, 32u * (uint32_t)tid, tag, v);
+                if (have_rec) s_rec[tid] = v;
+            }
+            if (__syncthreads_and(have_rec ? 1 : 0)) {
+                done = true;
+                break;
+            }
+            if (gave_up(spins)) break;
+        }
+        if (!done) return fail();
+        if (tid < 64) {
+            double S[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int m = tid; m < grid; m += 64) {
+                const double2 a = s_rec[2 * m], b = s_rec[2 * m + 1];
+                S[0] += a.x;
+                S[1] += a.y;
+                S[2] += b.x;
+                S[3] += b.y;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) S[c] = wave_sum_dpp(S[c]);
+            // (2) into every rank's inbox, this rank's own included
+            if (tid < 2 * R)
+                put_granules_sys(inbox_rec(tid >> 1) + 4 * (2 * ((int64_t)par * R + P.rank) + (tid & 1)), tag,
+                                 (tid & 1) == 0 ? make_double2(S[0], S[1]) : make_double2(S[2], S[3]));
+        }
+        __syncthreads();
+        // (3) every rank's sum
+        bool have_w = tid >= 2 * R;
+        done = false;
+        for (; spins < P.spin_limit; ++spins) {
+            if (!have_w) {
+                double2 v;
+                have_w = get_granules_sys(inbox_rec(P.rank) + 8 * (int64_t)par * R, 64u * (uint32_t)R, 32u * (uint32_t)tid,
+                                          tag, v);
+                if (have_w) s_rec[tid] = v;
+            }
+            if (__syncthreads_and(have_w ? 1 : 0)) {
+                done = true;
+                break;
+            }
+            if (gave_up(spins)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!done) return fail();
+        if (tid < 4) { // (4) rank order: the same bits on every rank
+            const double *rec = (const double *)s_rec;
+            double t = 0.0;
+            for (int r = 0; r < R; ++r) t += rec[4 * r + tid];
+            s_S[tid] = t;
+        }
+        __syncthreads();
+        if (tid < 2)
+            put_granules(P.grec + 4 * (2 * par + tid), tag,
+                         tid == 0 ? make_double2(s_S[0], s_S[1]) : make_double2(s_S[2], s_S[3]));
+        // the compute workgroups' stop decision, from the same bits (k_cg_persist, top of its loop)
+        const double rr = s_S[0];
+        if (j == 0) {
+            bb = rr;
+            target = P.stop_mode == 2 ? P.tol * sqrt(bb) : P.tol;
+        }
+        const double cost = P.stop_mode == 1 ? fabs(rr) : sqrt(rr);
+        const long long it_done = j - 1;
+        if ((j == 0 && bb == 0.0) || (it_done >= 1 && cost <= target) || !(fabs(rr) <= 1.79769313486231570e308) ||
+            it_done >= P.max_iter)
+            return;
+        __syncthreads(); // s_S and s_rec are rewritten by the next epoch
+        par ^= 1;
+        ++tag;
+    }
+}
+
 // Workgroup totals of four partial sums for the two publishing threads (0 and 1): DPP wave trees, then the eight
 // waves in order.
 __device__ inline void persist_block_sum(double (&acc)[4], double *s_red)
@@ -402,6 +510,11 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
     double *s_chunk = s_S + 4;
     auto t_xy = [&](int s) { return smem + (size_t)(gi + TG * s) * tile_words; };
 
+    const int cgrid = (int)gridDim.x - (MG ? P.comm_wg : 0); // compute workgroups (an exchange workgroup may follow them)
+    if (MG && P.comm_wg && (int)blockIdx.x == cgrid) {
+        persist_comm_loop(P, s_S, s_rec);
+        return;
+    }
     constexpr int NH = kPersistNh; // halo entries per thread: the workgroup's halo nodes are dealt out over ALL threads
     const unsigned tag0 = (MG ? P.tag_base : 0u) + 1u; // tag of epoch e: tag0 + e - 1
     int32_t node[NPT], deg[NPT], ent[NPT], oslot[NPT];
@@ -488,7 +601,7 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
     int par = 0;
     unsigned epoch = tag0; // the tags of successive exchanges
     if (tid < 2) // the block sums are in every thread: two threads publish the record's two pieces
-        put_granules(P.recg + 4 * (2 * ((int64_t)par * gridDim.x + blockIdx.x) + tid), epoch,
+        put_granules(P.recg + 4 * (2 * ((int64_t)par * cgrid + blockIdx.x) + tid), epoch,
                      tid == 0 ? make_double2(acc[0], acc[1]) : make_double2(acc[2], acc[3]));
     double2 hq[NH]; // q of this thread's halo nodes
     if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec)
@@ -595,7 +708,7 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
         ++epoch;
         ++j;
         if (tid < 2)
-            put_granules(P.recg + 4 * (2 * ((int64_t)par * gridDim.x + blockIdx.x) + tid), epoch,
+            put_granules(P.recg + 4 * (2 * ((int64_t)par * cgrid + blockIdx.x) + tid), epoch,
                          tid == 0 ? make_double2(acc[0], acc[1]) : make_double2(acc[2], acc[3]));
         if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec)
                : !persist_exchange<NH>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk))
