@@ -344,7 +344,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    if world > 1 and args.cg_variant == 2 and args.exchange in ("auto", "inboxes"):
+    if world > 1 and args.exchange in ("auto", "inboxes"):
         # Multi-GPU on-chip CG: every rank runs its share as one persistent launch and the per-iteration exchange goes
         # through per-rank inboxes in device memory (HIP IPC over xGMI) instead of a collective.  It cannot be
         # measured on the one-GPU development box, so the choice is made HERE, before anything is timed: one solve to
@@ -353,7 +353,7 @@ def main():
             import numpy as np
             ctx.run()
             t_inbox, st_in = timed_solve(), ctx.stats()
-            k_inbox, it_inbox = int(st_in["cg_kernel"]), int(st_in["iterations"])
+            k_inbox, it_inbox, ex_inbox = int(st_in["cg_kernel"]), int(st_in["iterations"]), int(st_in["exchange"])
             u_inbox = ctx.download()[0]
             barrier()
             ctx.close_inboxes()
@@ -364,12 +364,16 @@ def main():
             # all-reduce solve (same recurrence, so the same iteration count up to round-off at the threshold, and
             # displacements within the parity bar) on EVERY rank -- being faster is not enough
             du = float(np.linalg.norm(u_inbox - u_rccl) / max(np.linalg.norm(u_rccl), 1e-300))
-            same = all_agree(k_inbox == 2 and abs(it_inbox - it_rccl) <= max(2, it_rccl // 1000) and du <= 1e-8)
-            autotune = {"s_per_solve_inboxes": t_inbox, "kernel_with_inboxes": k_inbox, "s_per_solve_allreduce": t_rccl,
+            # (exchange 2: on-chip kernels through the inboxes; 3: the mesh does not fit the chips, streaming kernels
+            # through the inboxes; 1: the inbox path gave up and fell back)
+            same = all_agree(ex_inbox in (2, 3) and abs(it_inbox - it_rccl) <= max(2, it_rccl // 1000) and du <= 1e-8)
+            autotune = {"s_per_solve_inboxes": t_inbox, "kernel_with_inboxes": k_inbox, "exchange_with_inboxes": ex_inbox,
+                        "s_per_solve_allreduce": t_rccl,
                         "iterations_inboxes": it_inbox, "iterations_allreduce": it_rccl, "rel_l2_u_between_them": du,
                         "solutions_agree_on_every_rank": same}
             if same and (args.exchange == "inboxes" or t_inbox < t_rccl) and open_inboxes():
-                exchange = "per-rank inboxes in device memory (HIP IPC), on-chip CG on every rank"
+                exchange = ("per-rank inboxes in device memory (HIP IPC), " +
+                            ("on-chip CG on every rank" if ex_inbox == 2 else "streaming kernels (k_stream_exchange)"))
 
     for _ in range(args.warmup):
         ctx.run()
@@ -440,7 +444,7 @@ def main():
                        "elements": E, "nodes": N, "tile_nodes": args.tile, "cg_variant": args.cg_variant, "cg_kernel": kind, "cg_stop": args.stop, "cg_tol": args.tol,
                        "parallelism": f"hilbert-tile-ranges{world}" if world > 1 else "single",
                        "partition": args.partition if world > 1 else None,
-                       "exchange": exchange, "exchange_autotune": autotune,
+                       "exchange": exchange, "exchange_kind": int(st["exchange"]), "exchange_autotune": autotune,
                        "ranks": comm["ranks"], "transport": comm["transport"], "rccl_ranks": comm["rccl_ranks"]},
             "roofline": roofline,
             "spmv": spmv,

@@ -165,7 +165,8 @@ typedef struct mag_stats {
     int32_t lds_operator; /* 1: LDS-halo operator ran, 0: global-gather fallback */
     int32_t cg_kernel;    /* what ran the CG: 0 two launches per iteration, 1 one fused launch per iteration,
                              2 on-chip single launch, 3 CSR operator, 4 fp32 leg */
-    int32_t reserved;
+    int32_t exchange;     /* several ranks, how they traded per iteration: 0 one rank, 1 one all-reduce (RCCL or the test
+                             transport), 2 on-chip kernels through the inboxes, 3 streaming kernels through the inboxes */
     /* per-phase device time, HIP events on the context's stream, milliseconds */
     double ms_order;     /* Hilbert ordering + incidence + tile tables (symbolic, matrix-free op) */
     double ms_csr_symbolic;
@@ -261,7 +262,9 @@ int mag_comm_set_window(mag_ctx *ctx, void *host_ptr, uint64_t bytes);
  * inboxes of the ranks that read a value (across xGMI).  Every rank: mag_comm_inbox_create(ctx, bytes, handle) (bytes
  * as for the window; `handle` receives MAG_IPC_HANDLE_BYTES bytes), exchange the handles by any means, then
  * mag_comm_inbox_open(ctx, all_handles) with the nranks handles in rank order.  bytes = 0 removes the inboxes.
- * Each rank's launch ends with one exchange workgroup (no tile: it gathers the rank's partial sums, trades them with the
+ * When the mesh does not fit the chips the streaming kernels keep running one launch per iteration and trade through the
+ * same inboxes between launches (mag_stats.exchange = 3) instead of one all-reduce per iteration.
+ * Each rank's on-chip launch ends with one exchange workgroup (no tile: it gathers the rank's partial sums, trades them with the
  * other ranks through the inboxes and republishes the total) whenever a CU is free for it.
  * Exercised with up to eight ranks on ONE GPU only (~10 us per CG iteration with 8 ranks against ~40-90 through host
  * memory): measure before relying on it on a node, as bench.py does. */

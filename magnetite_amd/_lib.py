@@ -57,7 +57,7 @@ class Stats(C.Structure):
                 ("converged", C.c_int32), ("breakdown", C.c_int32), ("n_free", C.c_int64), ("nnz", C.c_int64),
                 ("num_tiles", C.c_int64), ("ell_entries", C.c_int64), ("halo_nodes", C.c_int64),
                 ("max_tile_halo", C.c_int32), ("lds_operator", C.c_int32), ("cg_kernel", C.c_int32),
-                ("reserved", C.c_int32), ("ms_order", C.c_double),
+                ("exchange", C.c_int32), ("ms_order", C.c_double),
                 ("ms_csr_symbolic", C.c_double), ("ms_element", C.c_double), ("ms_assemble", C.c_double),
                 ("ms_bc", C.c_double), ("ms_cg", C.c_double), ("ms_post", C.c_double), ("ms_total", C.c_double),
                 ("best_iteration", C.c_int64), ("termination", C.c_int32), ("persist_timeout", C.c_int32)]

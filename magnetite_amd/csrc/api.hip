@@ -135,7 +135,12 @@ struct mag_ctx {
     uint32_t solve_seq = 0;
     double best_cost = 0.0;   // argmin's best_param bookkeeping, as the CG phase that just ran reported it
     long long best_iter = 0;
-    bool persist_timed_out = false; // the on-chip kernel gave up at its grid barrier in this run (mag_stats.persist_timeout)
+    bool persist_timed_out = false;
+    // streaming kernels across GPUs: the per-iteration exchange through the device inboxes (k_stream_exchange) instead of
+    // an all-reduce; si_failed: a wait ran out once, this context uses the all-reduce from then on
+    bool si = false, si_failed = false;
+    uint32_t si_epoch = 0, si_tag_base = 0, si_spin = 1u << 20; // polls (~2 us each) before an exchange gives up
+    int32_t exchange_kind = 0; // mag_stats.exchange of the last run // the on-chip kernel gave up at its grid barrier in this run (mag_stats.persist_timeout)
     int nsums() const { return pre ? 5 : 4; }
     DevBuf xy32, hxy32, rqp32a, rqp32b, x32; // fp32 leg (mag_options.precision = 1)
     hipGraphExec_t graph = nullptr;
@@ -943,7 +948,14 @@ int fused_block(mag_ctx *ctx, int G)
     for (int i = 0; i < G; ++i) {
         const magk::FusedParams P = fused_params(ctx, i & 1);
         magk::fused_launch(P, ctx->B, ctx->fgrid, ctx->stream);
-        if (ctx->dist) {
+        if (ctx->dist && ctx->si) {
+            // the iteration's exchange through the device inboxes, in place on the buffer the launch just filled
+            ++ctx->si_epoch;
+            magk::stream_exchange_launch(P.part_out, ctx->g_all, ctx->n_iface, ctx->comm.rank, ctx->comm.nranks, ctx->own0,
+                                         ctx->own1, (int32_t)(ctx->si_epoch & 1u), ctx->si_tag_base + ctx->si_epoch,
+                                         ctx->si_spin, ctx->iface.as<int32_t>(), ctx->iface_readers.as<uint8_t>(),
+                                         ctx->inbox_peer, ctx->fstate.as<magk::FusedState>(), ctx->stream);
+        } else if (ctx->dist) {
             // the iteration's ONE collective, in place on the buffer the launch just filled:
             // [r.r, p.q, r.q, q.q partials, slot by slot | q on interface nodes (owner's value + zeros)]
             std::string msg;
@@ -1037,7 +1049,26 @@ int cg_phase_fused(mag_ctx *ctx)
     if (int rc = reserve_fused(ctx)) return rc;
     const int32_t stride = magk::kMaxGrid;
     HIPCHK(hipMemsetAsync(ctx->x.p, 0, 16 * (size_t)ctx->N, s));
+    ctx->si = false;
     if (ctx->dist) {
+        // The per-iteration exchange goes through the device inboxes when they are open and this solve streams (the
+        // mesh does not fit the chips, or the on-chip kernel is not wanted): k_stream_exchange instead of one RCCL
+        // all-reduce per iteration.  Same decision on every rank: it depends on replicated quantities only.
+        const int R = ctx->comm.nranks;
+        const char *e = getenv("MAG_TUNE_STREAM_INBOX");
+        ctx->si = R > 1 && R <= 8 && ctx->inbox_ready && !ctx->si_failed && !ctx->pre && (!e || atoi(e) != 0) &&
+                  ctx->inbox_bytes >= 64 + 128 * (size_t)R + 64 * (size_t)ctx->n_iface &&
+                  ctx->opt.max_iter < (int64_t(1) << 24) - 4;
+        if (ctx->si) {
+            ctx->solve_seq = (ctx->solve_seq + 1) & 0xffu;
+            if (ctx->solve_seq == 0) ctx->solve_seq = 1;
+            ctx->si_tag_base = ctx->solve_seq << 24;
+            ctx->si_epoch = 0;
+            ctx->si_spin = 1u << 20;
+            if (const char *sp = getenv("MAG_TUNE_STREAM_SPIN")) ctx->si_spin = (uint32_t)atoi(sp); // tests: force the fallback
+            // nothing of an earlier use of the inbox may look current: cleared before the all-reduce below lines the ranks up
+            HIPCHK(hipMemsetAsync(ctx->inbox_own, 0, 64 + 128 * (size_t)R + 64 * (size_t)ctx->n_iface, s));
+        }
         // b.b partials go straight into exchange buffer 0 (its q part = q_{-1} = 0), summed over ranks in place
         double *c0 = ctx->comm_f.as<double>();
         HIPCHK(hipMemsetAsync(c0, 0, 8 * 2 * ctx->cwords, s));
@@ -1061,6 +1092,7 @@ int cg_phase_fused(mag_ctx *ctx)
     const bool graph = ctx->opt.use_graph != 0 && !ctx->dist;
     if (graph)
         if (int rc = ensure_fused_graph(ctx, G)) return rc;
+    ctx->exchange_kind = ctx->dist ? (ctx->si ? 3 : 1) : 0;
     // iterate j is produced by launch j and judged by launch j+1: two launches more than iterations
     const long long max_blocks = (long long)(ctx->opt.max_iter / G) + 3;
     bool done = false;
@@ -1078,6 +1110,23 @@ int cg_phase_fused(mag_ctx *ctx)
             done = ctx->h_fstate[slot ^ 1].done != 0;
         }
         slot ^= 1;
+    }
+    if (ctx->si) {
+        // did any rank's exchange give up?  All ranks must agree before anyone changes path (as for the on-chip kernel)
+        HIPCHK(hipMemcpyAsync(&ctx->h_fstate[2], ctx->fstate.p, sizeof(FusedState), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        double flag = (ctx->h_fstate[2].exchange_timeout || !ctx->h_fstate[2].done) ? 1.0 : 0.0;
+        std::string msg;
+        HIPCHK(hipMemcpyAsync(ctx->comm_pq.p, &flag, 8, hipMemcpyHostToDevice, s));
+        if (int rc = ctx->comm.allreduce_sum(ctx->comm_pq.as<double>(), 1, s, msg)) return fail(ctx, rc, "%s", msg.c_str());
+        HIPCHK(hipMemcpyAsync(&flag, ctx->comm_pq.p, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (flag != 0.0) {
+            HIPCHK(hipMemsetAsync(ctx->inbox_own, 0, 64, s)); // the timeout word
+            ctx->si_failed = true;
+            if (ctx->opt.verbose) printf("info: inbox exchange timed out, falling back to one all-reduce per iteration\n");
+            return cg_phase_fused(ctx);
+        }
     }
     if (ctx->dist)
         if (int rc = gather_solution(ctx)) return rc;
@@ -1229,6 +1278,7 @@ int cg_phase_persist(mag_ctx *ctx)
         return cg_phase_fused(ctx);
     }
     ctx->cg_kernel = 2;
+    ctx->exchange_kind = mg ? 2 : 0;
     if (mg) { // every rank returns the whole solution
         if (int rc = gather_solution(ctx)) return rc;
         HIPCHK(hipStreamSynchronize(s));
@@ -1747,6 +1797,7 @@ int mag_run(mag_ctx *ctx)
                     "preconditioner needs the fused LDS iteration: cg_variant 1, precision fp64, matrix-free operator, "
                     "every tile within LDS");
     ctx->cg_kernel = csr_op ? 3 : (f32 ? 4 : (ctx->fused ? 1 : 0));
+    ctx->exchange_kind = ctx->dist ? 1 : 0; // the phases that trade through the inboxes say so themselves
     ctx->persist_timed_out = false;
     auto cg_dispatch = [&]() {
         return csr_op ? cg_phase_csr(ctx)
@@ -1815,6 +1866,7 @@ int mag_run(mag_ctx *ctx)
     st.max_tile_halo = ctx->max_halo;
     st.lds_operator = ctx->use_lds ? 1 : 0;
     st.cg_kernel = ctx->cg_kernel;
+    st.exchange = ctx->exchange_kind;
     st.n_free = ctx->nf;
     ctx->have_run = true;
     st.persist_timeout = ctx->persist_timed_out ? 1 : 0;

@@ -1503,6 +1503,7 @@ __global__ void __launch_bounds__(256) k_fused_setup(const double *part, int nPa
         st->breakdown = 0;
         st->best_cost = __builtin_inf();
         st->best_iter = 0;
+        st->exchange_timeout = 0;
         st->done = (bb == 0.0) ? 1 : 0; // b == 0: x = 0 (documented deviation)
         st->converged = (bb == 0.0) ? 1 : 0;
         if (bb == 0.0) st->final_cost = 0.0;

@@ -237,7 +237,9 @@ struct FusedState {
     int done, converged, breakdown, stop_mode;
     double best_cost;    // as in CgState
     long long best_iter;
-    double pad[4];
+    int exchange_timeout; // multi-GPU, inbox exchange of the streaming kernels: a wait ran out (k_stream_exchange)
+    int pad0;
+    double pad[3];
 };
 struct FusedParams {
     int64_t N;
@@ -332,6 +334,11 @@ struct PersistParams {
     const uint8_t *iface_readers; // n_iface: bit r set when rank r reads the interface node of that slot
     unsigned long long *grec;    // device: 2 * 8 granules, the grid-wide sums republished by workgroup 0
 };
+// multi-GPU, streaming kernels: the per-iteration exchange [dot partials | interface q] through the ranks' device
+// inboxes instead of an all-reduce, in place on `buf` (persist.hip, k_stream_exchange)
+void stream_exchange_launch(double *buf, int32_t g_all, int32_t n_iface, int32_t rank, int32_t nranks, int32_t own0,
+                            int32_t own1, int32_t par, uint32_t tag, uint32_t spin_limit, const int32_t *iface,
+                            const uint8_t *iface_readers, void *const *inboxes, FusedState *st, hipStream_t s);
 int persist_tiles_per_wg(int32_t B); // tiles one workgroup keeps on chip (0: tile size not supported)
 size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh);
 void persist_launch(const PersistParams &P, int32_t B, int32_t grid, hipStream_t s); // MG kernel when nranks > 1

@@ -744,6 +744,156 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
     }
 }
 
+// ========================================= inbox exchange for the STREAMING kernels ===
+// Meshes the chips cannot hold (more than ~0.5M nodes per GPU: BASELINE config 5 on 8 GPUs) run one fused launch per CG
+// iteration, and the ranks must trade [dot partials | q on the interface nodes] between launches.  One RCCL all-reduce
+// does that in 20-30 us; this kernel does it through the same per-rank inboxes the on-chip kernel uses (device memory,
+// mapped by the peers; tagged granules, polls in local HBM), in place on the buffer the iteration kernel just filled --
+// a drop-in for the all-reduce, the iteration kernels are untouched:
+//   * q of an interface node this rank owns goes to the inboxes of the ranks that read it (reader mask);
+//   * block 0 adds the rank's G partial slots in a fixed order and stores the rank's four sums into every inbox;
+//   * block 0 waits for the R sums, adds them in rank order (the same bits on every rank) and writes the total into slot 0
+//     of each partial array, clearing the other slots: the next launch's sum over the slots is the total; every block
+//     waits for the q of its share of the interface nodes this rank reads and writes them into the buffer; slots the
+//     rank neither owns nor reads get 0.
+// Epochs alternate between two parities of the inbox; nobody can be two exchanges ahead of a rank that has not finished
+// reading (it would need that rank's next sums first).  Every wait is bounded: a rank that gives up raises
+// FusedState::exchange_timeout (and the other ranks' timeout words) and the host falls back to the all-reduce.
+struct StreamExchangeParams {
+    double *buf;              // [4 x g_all partial slots | n_iface x double2 q]: the iteration kernel's output, in place
+    int32_t g_all, n_iface, rank, nranks, own0, own1, par;
+    uint32_t tag, spin_limit;
+    const int32_t *iface;     // sorted Hilbert ids of the interface nodes
+    const uint8_t *iface_readers;
+    uint8_t *inbox[8];
+    FusedState *st;
+};
+
+__global__ void __launch_bounds__(256) k_stream_exchange(const StreamExchangeParams P)
+{
+    __shared__ double s_red[4][4];
+    __shared__ double2 s_recs[16];
+    const int tid = threadIdx.x, R = P.nranks;
+    if (P.st->done) return; // converged (or capped) earlier in this block: every rank takes the same exit
+    uint8_t *mine = P.inbox[P.rank];
+    gu32 *wtmo = (gu32 *)mine;
+    double2 *q = (double2 *)(P.buf + 4 * (size_t)P.g_all);
+    const size_t qoff = 64 + 128 * (size_t)R;
+    // (1) this rank's interface q to their readers
+    for (int32_t k = blockIdx.x * 256 + tid; k < P.n_iface; k += gridDim.x * 256) {
+        const int32_t g = P.iface[k];
+        if (g < P.own0 || g >= P.own1) continue;
+        const uint32_t readers = P.iface_readers[k];
+        const double2 v = q[k];
+        for (int r = 0; r < R; ++r)
+            if (r != P.rank && ((readers >> r) & 1u))
+                put_granules_sys((unsigned long long *)(P.inbox[r] + qoff + 32 * ((size_t)P.par * P.n_iface + k)), P.tag, v);
+    }
+    // (2) block 0: the rank's sums, fixed order (thread-strided partials, wave trees, the four waves in order)
+    if (blockIdx.x == 0) {
+        double S[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = tid; i < P.g_all; i += 256) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) S[c] += P.buf[(size_t)c * P.g_all + i];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) S[c] = wave_sum_dpp(S[c]);
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s_red[c][tid >> 6] = S[c];
+        }
+        __syncthreads();
+        if (tid < 2 * R) {
+            double T[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) T[c] = ((s_red[c][0] + s_red[c][1]) + s_red[c][2]) + s_red[c][3];
+            put_granules_sys((unsigned long long *)(P.inbox[tid >> 1] + 64) + 4 * (2 * ((int64_t)P.par * R + P.rank) + (tid & 1)),
+                             P.tag, (tid & 1) == 0 ? make_double2(T[0], T[1]) : make_double2(T[2], T[3]));
+        }
+    }
+    // (3) wait: the R sums (every block) and the q this rank reads (each block its share of the slots)
+    const unsigned long long *wrec = (const unsigned long long *)(mine + 64) + 8 * (int64_t)P.par * R;
+    const unsigned long long *wq = (const unsigned long long *)(mine + qoff) + 4 * (int64_t)P.par * P.n_iface;
+    bool have_w = tid >= 2 * R || blockIdx.x != 0; // only block 0 turns the sums into the next launch's input
+    int32_t k = blockIdx.x * 256 + tid; // one slot at a time per thread
+    bool ok_all = false;
+    for (unsigned spins = 0; spins < P.spin_limit; ++spins) {
+        if (!have_w) {
+            double2 v;
+            have_w = get_granules_sys(wrec, 64u * (uint32_t)R, 32u * (uint32_t)tid, P.tag, v);
+            if (have_w) s_recs[tid] = v;
+        }
+        while (k < P.n_iface) { // advance over the slots that are settled; stop at the first one still on its way
+            const int32_t g = P.iface[k];
+            const bool owned = g >= P.own0 && g < P.own1;
+            if (!owned) {
+                if ((P.iface_readers[k] >> P.rank) & 1u) {
+                    double2 v;
+                    if (!get_granules_sys(wq, 32u * (uint32_t)P.n_iface, 32u * (uint32_t)k, P.tag, v)) break;
+                    q[k] = v;
+                } else {
+                    q[k] = make_double2(0.0, 0.0);
+                }
+            }
+            k += gridDim.x * 256;
+        }
+        if (__syncthreads_and((have_w && k >= P.n_iface) ? 1 : 0)) {
+            ok_all = true;
+            break;
+        }
+        if ((spins & 255u) == 255u) {
+            const int dead = tid == 0 && __hip_atomic_load(wtmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u ? 1 : 0;
+            if (__syncthreads_or(dead)) break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if (!ok_all) {
+        if (tid == 0) { // the solve is over for this rank: every later launch of the block exits at once, the host sees
+            P.st->exchange_timeout = 1; // `done`, finds the flag and lets the ranks agree on the all-reduce path
+            P.st->done = 1;
+        }
+        if (tid < R) __hip_atomic_store((gu32 *)P.inbox[tid], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    // (4) block 0: totals in rank order into slot 0, the other slots cleared
+    if (blockIdx.x == 0) {
+        if (tid < 4) {
+            const double *rec = (const double *)s_recs;
+            double t = 0.0;
+            for (int r = 0; r < R; ++r) t += rec[4 * r + tid];
+            P.buf[(size_t)tid * P.g_all] = t;
+        }
+        for (int i = 1 + tid; i < P.g_all; i += 256) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) P.buf[(size_t)c * P.g_all + i] = 0.0;
+        }
+    }
+}
+
+void stream_exchange_launch(double *buf, int32_t g_all, int32_t n_iface, int32_t rank, int32_t nranks, int32_t own0,
+                            int32_t own1, int32_t par, uint32_t tag, uint32_t spin_limit, const int32_t *iface,
+                            const uint8_t *iface_readers, void *const *inboxes, FusedState *st, hipStream_t s)
+{
+    StreamExchangeParams P = {};
+    P.buf = buf;
+    P.g_all = g_all;
+    P.n_iface = n_iface;
+    P.rank = rank;
+    P.nranks = nranks;
+    P.own0 = own0;
+    P.own1 = own1;
+    P.par = par;
+    P.tag = tag;
+    P.spin_limit = spin_limit;
+    P.iface = iface;
+    P.iface_readers = iface_readers;
+    for (int r = 0; r < nranks && r < 8; ++r) P.inbox[r] = (uint8_t *)inboxes[r];
+    P.st = st;
+    int blocks = (n_iface + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 32 ? 32 : blocks);
+    k_stream_exchange<<<blocks, 256, 0, s>>>(P);
+}
+
 int persist_tiles_per_wg(int32_t B) { return B == 256 || B == 512 ? kPersistNpt * (kPersistThreads / B) : 0; }
 
 size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh)

@@ -101,8 +101,10 @@ def case(built):
     return p, ref, single
 
 
-def check(case, results, kernel):
+def check(case, results, kernel, exchange=None):
     p, ref, single = case
+    if exchange is not None:
+        assert all(o["exchange"] == exchange for outs in results for o in outs), [outs[0]["exchange"] for outs in results]
     k = p.u_known == 1
     for rank, outs in enumerate(results):
         for out in outs:
@@ -126,13 +128,22 @@ def check(case, results, kernel):
 
 
 def test_eight_ranks_streaming_kernels_one_allreduce_per_iteration(case):
-    check(case, run_ranks(case[0], inboxes=False, cg_variant=1, tile_nodes=512), kernel=1)
+    check(case, run_ranks(case[0], inboxes=False, cg_variant=1, tile_nodes=512), kernel=1, exchange=1)
+
+
+def test_eight_ranks_streaming_kernels_exchange_through_inboxes(case, monkeypatch):
+    """meshes the chips cannot hold stream (BASELINE config 5 on 8 GPUs: 1M nodes per GPU); with the inboxes open the
+    per-iteration exchange of the streaming kernels goes through them too (k_stream_exchange) instead of an all-reduce;
+    then with every wait cut short: the ranks agree to fall back to the all-reduce and still return the right answer"""
+    check(case, run_ranks(case[0], inboxes=True, solves=2, cg_variant=1, tile_nodes=512), kernel=1, exchange=3)
+    monkeypatch.setenv("MAG_TUNE_STREAM_SPIN", "0")
+    check(case, run_ranks(case[0], inboxes=True, cg_variant=1, tile_nodes=512), kernel=1, exchange=1)
 
 
 def test_eight_ranks_on_chip_kernels_exchange_through_inboxes(case):
     """22-23 tiles per rank, one workgroup each: the eight persistent launches are co-resident on the 256 CUs and meet
     every iteration through their inboxes; two solves in a row (fresh tags, inboxes cleared between them)"""
-    check(case, run_ranks(case[0], inboxes=True, solves=2, cg_variant=2, tile_nodes=512), kernel=2)
+    check(case, run_ranks(case[0], inboxes=True, solves=2, cg_variant=2, tile_nodes=512), kernel=2, exchange=2)
 
 
 def test_eight_ranks_agree_to_fall_back(case, monkeypatch):

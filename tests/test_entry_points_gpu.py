@@ -106,6 +106,24 @@ def test_bench_multi_rank_code_path_on_one_gpu(built, window):
         assert ("inboxes" in d["config"]["exchange"]) == faster
 
 
+def test_bench_streaming_kernels_exchange_through_inboxes(built):
+    """--cg-variant 1 --exchange inboxes: what a mesh too large for the chips gets (BASELINE config 5 on 8 GPUs) -- the
+    streaming kernels trade through the device inboxes (k_stream_exchange, exchange_kind 3), kept only because the trial
+    solve reproduced the all-reduce solve on both ranks."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29613", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu",
+           "--workload", "plate100k", "--steps", "1", "--warmup", "1", "--op-reps", "20", "--cg-variant", "1",
+           "--exchange", "inboxes"]
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    tune = d["config"]["exchange_autotune"]
+    assert tune["exchange_with_inboxes"] == 3 and tune["solutions_agree_on_every_rank"] is True
+    assert d["config"]["exchange_kind"] == 3 and d["config"]["cg_kernel"] == 1 and "k_stream_exchange" in d["config"]["exchange"]
+    assert d["cg_converged"] == 1 and d["verify"]["ok_on_every_rank"] is True
+
+
 def test_bench_strong_partition_keeps_the_baseline_size(built):
     """--partition strong: the workload at its BASELINE size split over the ranks (configs 4 and 5 are `--gpus 4
     --workload plate4m --partition strong` and `--gpus 8 --workload multihole16m --partition strong`); rehearsed with
