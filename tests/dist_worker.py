@@ -28,6 +28,9 @@ def main():
                     help="on-chip CG on every rank: 1 = exchange through a shared host-memory window, 2 = through "
                          "per-rank inboxes in device memory (HIP IPC)")
     ap.add_argument("--expect-kernel", type=int, default=2, help="with --window: mag_stats.cg_kernel every rank must report")
+    ap.add_argument("--stream-inbox", action="store_true",
+                    help="with --window 2: keep the streaming kernels (cg_variant 1); their per-iteration exchange then goes "
+                         "through the inboxes (k_stream_exchange, mag_stats.exchange 3) instead of an all-reduce")
     ap.add_argument("--stacked", type=int, default=0, help="bench.py's weak-scaling geometry: plate-with-hole stacked N times")
     a = ap.parse_args()
     import torch
@@ -69,7 +72,8 @@ def main():
                 shm = shared_memory.SharedMemory(name=names[0])
                 from multiprocessing import resource_tracker
                 resource_tracker.unregister(shm._name, "shared_memory")  # rank 0 owns the segment (Python < 3.13)
-        with Context(device=0, tile_nodes=a.tile, cg_variant=2 if a.window else a.variant, preconditioner=a.precond) as c:
+        with Context(device=0, tile_nodes=a.tile, cg_variant=2 if (a.window and not a.stream_inbox) else a.variant,
+                     preconditioner=a.precond) as c:
             c.init_callback(allreduce, rank, world)
             if shm is not None:
                 c.set_window(shm)
@@ -79,6 +83,8 @@ def main():
                 c.open_inboxes(handles)
             out = c.solve(prob)
             kernel = c.stats()["cg_kernel"]
+            if a.stream_inbox:
+                assert c.stats()["exchange"] == 3, c.stats()["exchange"]
             if a.window:
                 print(f"rank {rank}: on-chip across ranks: {out['iterations']} iterations, "
                       f"{c.stats()['ms_cg'] * 1e3 / max(1, out['iterations']):.2f} us per iteration", flush=True)

@@ -50,6 +50,15 @@ def test_on_chip_cg_across_ranks_through_device_inboxes(built, nproc):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+@pytest.mark.parametrize("nproc", [2, 4])
+def test_streaming_kernels_exchange_through_device_inboxes(built, nproc):
+    """k_stream_exchange with one PROCESS per rank: the inboxes are real HIP IPC mappings (same device here); streaming
+    kernels, one exchange launch per iteration instead of an all-reduce; two solves in a row give the same bits."""
+    r = launch(nproc, "callback", 29601 + nproc, 1,
+               ("--window", "2", "--stream-inbox", "--tile", "512", "--mesh", "120", "--expect-kernel", "1"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 @pytest.mark.parametrize("nproc", [2, 3])
 def test_on_chip_cg_across_ranks_through_a_host_window(built, nproc):
     """Every rank runs its share of the mesh as one persistent launch; per iteration the ranks exchange one record of
