@@ -58,3 +58,31 @@ def solve(xy, conn, u_known, u_in, f_in, youngs, nu, t):
         s = D @ strain_displacement(xy, tri, element_area(xy, tri)) @ ue
         stress[e] = np.hypot(s[0], s[1]) * (-1.0 if s[0] + s[1] < 1.0 else 1.0)  # the `< 1.0` quirk, solver.rs:524-530
     return dict(K=K, b=b, u=u, f=f, stress=stress, free=free, known=known)
+
+
+def argmin_cg(A, b, target, max_iter, squared=False):
+    """argmin 0.10 `ConjugateGradient` under `Executor`, as the reference configures it (solver.rs:139-176), restated from
+    the published algorithm with numpy vector operations: x0 = 0, r0 = -(b - A x0), p0 = -r0, and per iteration
+    q = A p, alpha = r.r / p.q, x += alpha p, r += alpha q, beta = r'.r' / r.r, p = -r' + beta p, cost = |r'| (or r'.r').
+    The executor stops once best_cost <= target or after max_iter iterations and returns best_param, the lowest-cost
+    iterate.  Returns (best_param, iterations, cost history)."""
+    x = np.zeros_like(b)
+    r = -(b - A @ x)
+    p = -r
+    rtr = float(r @ r)
+    best, x_best, hist = np.inf, x.copy(), []
+    it = 0
+    while it < max_iter and not best <= target:
+        q = A @ p
+        alpha = rtr / float(p @ q)
+        x = x + alpha * p
+        r = r + alpha * q
+        rtr_new = float(r @ r)
+        p = -r + (rtr_new / rtr) * p
+        rtr = rtr_new
+        cost = abs(rtr) if squared else np.sqrt(rtr)
+        hist.append(cost)
+        it += 1
+        if cost < best:
+            best, x_best = cost, x.copy()
+    return x_best, it, np.array(hist)

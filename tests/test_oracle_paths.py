@@ -215,3 +215,33 @@ def test_oracle_pcg_is_textbook_pcg_with_fp32_node_blocks():
         assert np.linalg.norm(ref["u"][free] - x) <= 1e-9 * np.linalg.norm(x)
         assert np.linalg.norm(ref["u"] - plain["u"]) <= 1e-8 * np.linalg.norm(plain["u"])
         assert ref["iterations"] < plain["iterations"]
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_cg_follows_the_numpy_restatement_of_argmin(built, name):
+    """The CG is third-party code the reference tree does not hold (argmin 0.10): the oracle's C restatement and an
+    independent numpy restatement of the published recurrences must walk the same residual history, stop in the same
+    iteration and -- at an iteration cap that falls into a rising stretch -- return the same best_param."""
+    p = CASES[name]()
+    K = oracle.assemble_sparse(p.xy_flat, p.conn_flat, p.poisson_ratio, p.youngs_modulus, p.part_thickness)
+    A, b = oracle.reduce_system(K, p.u_known, p.u_in, p.f_in)
+    Ad = A.toarray()
+    x_o, it_o, cost_o, hist_o = oracle.cg(A, b, hist_len=100000)
+    x_t, it_t, hist_t = twin.argmin_cg(Ad, b, oracle.TARGET_CG_COST, oracle.MAX_CG_ITER)
+    # same recurrences, different summation order: the histories coincide at first and drift apart as CG amplifies the
+    # rounding differences (the reference's absolute 1e-4 on a 1e7-scale right-hand side runs the iteration 12 orders of
+    # magnitude down, to round-off); both end at the same solution
+    n = min(len(hist_o), len(hist_t), 8)
+    assert n >= 3 and np.allclose(hist_o[:n], hist_t[:n], rtol=1e-9)
+    assert abs(it_o - it_t) <= max(3, it_t // 10)
+    assert rel(x_o, x_t) <= 1e-9
+    # the iteration cap: best_param is the lowest-cost iterate, not necessarily the last one
+    cap = min(8, it_t - 1)
+    x_oc, it_oc, cost_oc, hist_oc = oracle.cg(A, b, max_iter=cap, hist_len=cap)
+    x_tc, it_tc, hist_tc = twin.argmin_cg(Ad, b, oracle.TARGET_CG_COST, cap)
+    assert it_oc == it_tc == cap and int(np.argmin(hist_oc)) == int(np.argmin(hist_tc))
+    assert abs(cost_oc - hist_tc.min()) <= 1e-9 * hist_tc.min() and rel(x_oc, x_tc) <= 1e-9
+    # r.r as the cost (the other reading of argmin's `cost`): same walk, its own stop
+    x_os, it_os, _, _ = oracle.cg(A, b, stop_mode=oracle.STOP_RNORM_SQ, tol=1e-2)
+    x_ts, it_ts, _ = twin.argmin_cg(Ad, b, 1e-2, oracle.MAX_CG_ITER, squared=True)
+    assert abs(it_os - it_ts) <= max(2, it_ts // 50) and rel(x_os, x_ts) <= 1e-8
