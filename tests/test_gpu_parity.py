@@ -532,6 +532,13 @@ def test_random_unstructured_meshes(built, seed):
         c.upload_problem(p)
         assert np.array_equal(c.element_stiffness(), oracle.element_stiffness_all(
             p.xy_flat, p.conn_flat, p.poisson_ratio, p.youngs_modulus, p.part_thickness))
+        # mixed valences (5 ... 9+): rows on both sides of the assembly's 8-block accumulators, pattern from the incidence lists
+        rowptr, col, val = c.assemble_csr()
+        K = oracle.assemble_sparse(p.xy_flat, p.conn_flat, p.poisson_ratio, p.youngs_modulus, p.part_thickness)
+        assert np.array_equal(rowptr.astype(np.int64), K.rowptr) and np.array_equal(col, K.col) and np.array_equal(val, K.val)
+        rp, cf, vf, b = c.reduce_system()
+        A, bo = oracle.reduce_system(K, p.u_known, p.u_in, p.f_in)
+        assert np.array_equal(cf, A.col) and np.array_equal(vf, A.val) and np.array_equal(b, bo)
         out = c.solve(p)
     assert out["converged"] == 1
     assert rel(out["u"], ref["u"]) <= TOL_U
