@@ -7,10 +7,13 @@ whose flat arrays are already resident in HBM (mag_upload happens before the tim
 
   N = 1 : BASELINE config 3, the configuration the metric is quoted on: ~1M-triangle plate with a hole,
           left edge fixed, right edge ux = delta, CG to relative residual 1e-8.
-  N > 1 : MUST be started under torch.distributed.run (one process per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
-          from the environment):
+  N > 1 : one process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), either started under
+          the launcher,
               python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
                   bench.py --gpus N --steps K --warmup W
+          or bare, `python bench.py --gpus N ...`: the parent then starts exactly that command as a fresh child process
+          BEFORE it has imported torch or touched the GPU (a process that has initialised HIP is never re-exec'ed), lets
+          rank 0's single JSON line through and exits with the children's code.
           weak scaling (default): every GPU owns ~1M triangles of one global plate N times as tall; ranks own contiguous
           Hilbert-tile ranges; per CG iteration ONE exchange of [dot partials | q on interface nodes].
           --partition strong: the workload at its BASELINE size split over the N GPUs (configs 4 and 5).
@@ -32,7 +35,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.65  # half the guide's 157.3 TFLOP/s fp32 vector peak: 256 CUs x 4 SIMDs x 16 fp64 FMA lanes
 INFINITY_CACHE_BYTES = 256 << 20
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_summary.json")  # scripts/pmc_summarize.py (not round-specific)
+CPU_RECORD = os.path.join(ROOT, "profiles", "cpu_baseline.json")  # scripts/cpu_baseline_record.py
 
 
 def bytes_spmv(E, N):
@@ -59,9 +63,23 @@ def flops_iteration(E, N):
     return 110.0 * E + 20.0 * N
 
 
+def pmc_is_stale():
+    """The committed counters describe the kernels of ONE build: scripts/pmc_summarize.py records the digest of the kernel
+    sources the profiled library was linked from, csrc/Makefile writes the digest of the library loaded here next to it.
+    True when they differ (or either is missing): the counters are then of other code than the one being timed."""
+    from magnetite_amd import _lib
+    if not os.path.exists(PMC_SUMMARY):
+        return True
+    recorded = json.load(open(PMC_SUMMARY)).get("_meta", {}).get("source_hash")
+    return recorded is None or recorded != _lib.built_source_hash()
+
+
 def load_pmc(key):
     if os.path.exists(PMC_SUMMARY):
-        return json.load(open(PMC_SUMMARY)).get(key)
+        e = json.load(open(PMC_SUMMARY)).get(key)
+        if e is not None:
+            e = dict(e, stale=pmc_is_stale())
+        return e
     return None
 
 
@@ -87,38 +105,104 @@ def build_problem(workload, n_gpus):
     raise SystemExit(f"unknown workload {workload}")
 
 
-def cpu_baseline(prob, gpu_iterations, stop_mode, tol, sample_iters):
-    """Oracle (C restatement of solver.rs, sparse path, 1 thread) timed on a bounded sample of the same workload:
-    full K_e + CSR assembly + BC elimination, then `sample_iters` CG iterations; CG time is scaled to the
-    iteration count the GPU needed (the oracle runs the same recurrence)."""
+def usable_cores():
+    """Host cores this process may actually run on: the scheduler affinity mask, cut to the cgroup's CPU quota when
+    one is set (a GPU box hands a 1-GPU job a share of the host, not all of it)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(prob, gpu_iterations, stop_mode, tol, sample_iters, threads=0):
+    """Oracle (C restatement of solver.rs, sparse path) timed on a bounded sample of the same workload, twice:
+    1 thread (the reference is single-threaded) and OpenMP on every core this process may use.  Each leg:
+    full K_e + CSR assembly + BC elimination (timed around the C calls), then a sample of CG iterations; the CG time is
+    scaled to the iteration count the GPU needed (the oracle runs the same recurrence)."""
+    import ctypes as C
+
+    import numpy as np
+
     import oracle
-    t0 = time.perf_counter()
-    K = oracle.assemble_sparse(prob.xy_flat, prob.conn_flat, prob.poisson_ratio, prob.youngs_modulus,
-                               prob.part_thickness)
-    A, b = oracle.reduce_system(K, prob.u_known, prob.u_in, prob.f_in)
+    L = oracle.lib()
+    xy, conn = oracle._prep(prob.xy_flat, prob.conn_flat)
+    N, E = xy.size // 2, conn.size // 3
+    uk = np.ascontiguousarray(prob.u_known, dtype=np.uint8)
+    ui, fi = np.ascontiguousarray(prob.u_in, dtype=np.float64), np.ascontiguousarray(prob.f_in, dtype=np.float64)
+    nf = int(2 * N - uk.sum())
+
+    def assemble(omp):
+        b = np.zeros(max(nf, 1))
+        fa = L.orc_assemble_sparse_omp if omp else L.orc_assemble_sparse
+        fr = L.orc_reduce_system_omp if omp else L.orc_reduce_system
+        t0 = time.perf_counter()
+        K = fa(N, E, oracle._d(xy), oracle._i(conn), float(prob.poisson_ratio), float(prob.youngs_modulus),
+               float(prob.part_thickness))
+        A = fr(K, oracle._b(uk), oracle._d(ui), oracle._d(fi), oracle._d(b))
+        dt = time.perf_counter() - t0
+        L.orc_csr_free(K)
+        return oracle.Csr(A), b[:nf], dt
+
+    A, b, t_asm = assemble(False)
     t1 = time.perf_counter()
     _, it, _, _ = oracle.cg(A, b, stop_mode=stop_mode, tol=tol, max_iter=sample_iters)
-    t2 = time.perf_counter()
-    per_iter = (t2 - t1) / max(it, 1)
-    total = (t1 - t0) + per_iter * gpu_iterations
-    E = prob.mesh.num_elements
-    # all-cores variant of the CG (OpenMP rows + reductions); the reference itself is single-threaded
-    cores = max(1, min(16, os.cpu_count() or 1))  # the GPU box's CPU share for one GPU
+    per_iter = (time.perf_counter() - t1) / max(it, 1)
+    total = t_asm + per_iter * gpu_iterations
+    cores = threads or usable_cores()
+    oracle.set_threads(cores)
+    A2, b2, t_asm_par = assemble(True)
+    same = bool(np.array_equal(A2.val, A.val) and np.array_equal(A2.col, A.col) and np.array_equal(b2, b))
     t3 = time.perf_counter()
     _, itp, _ = oracle.cg_parallel(A, b, stop_mode=stop_mode, tol=tol, max_iter=sample_iters * 4, threads=cores)
-    t4 = time.perf_counter()
-    per_iter_par = (t4 - t3) / max(itp, 1)
-    total_par = (t1 - t0) + per_iter_par * gpu_iterations
+    per_iter_par = (time.perf_counter() - t3) / max(itp, 1)
+    total_par = t_asm_par + per_iter_par * gpu_iterations
     return {
         "all_cores": {"value": E / total_par, "unit": "elements/s", "cores": cores, "kind": "port",
-                      "cg_iters_per_s": 1.0 / per_iter_par,
-                      "sample": f"same assembly (1 thread) + {itp} OpenMP CG iterations ({per_iter_par * 1e3:.2f} ms each)"},
+                      "cores_on_host": os.cpu_count(),
+                      "cores_rule": "affinity mask cut to the cgroup CPU quota (usable_cores)" if not threads else "--cpu-threads",
+                      "assembly_elements_per_s": E / t_asm_par, "cg_iters_per_s": 1.0 / per_iter_par,
+                      "assembly_bit_identical_to_1_thread": same,
+                      "sample": f"OpenMP K_e+CSR assembly+BC elimination over row nodes ({t_asm_par:.3f} s) + {itp} OpenMP "
+                                f"CG iterations ({per_iter_par * 1e3:.2f} ms each), {cores} threads, CG scaled to the "
+                                f"{gpu_iterations} iterations of the GPU solve"},
         "value": E / total, "unit": "elements/s", "cores": 1, "kind": "port",
         "sample": f"oracle/magnetite_oracle.c on the same mesh: full K_e+CSR assembly+BC elimination "
-                  f"({t1 - t0:.2f} s) + {it} CG iterations ({per_iter * 1e3:.2f} ms each), CG scaled to the "
+                  f"({t_asm:.2f} s) + {it} CG iterations ({per_iter * 1e3:.2f} ms each), CG scaled to the "
                   f"{gpu_iterations} iterations of the GPU solve",
-        "assembly_elements_per_s": E / (t1 - t0), "cg_iters_per_s": 1.0 / per_iter,
+        "assembly_elements_per_s": E / t_asm, "cg_iters_per_s": 1.0 / per_iter,
     }
+
+
+def fixture_parity(workload, prob, u, f, stress, iterations, stop, tol):
+    """This rank's returned solution against the oracle's sampled solution of the workload at BASELINE size
+    (tests/golden/fullsize_<workload>.npz, generator tests/golden/make_fullsize_fixtures.py): the mesh must be the
+    fixture's (sizes and checksums), the iteration count the oracle's, u within 1e-8 relative L2 at the sampled DOFs,
+    reactions and stress within 1e-7 (first differences of an iterative solution: tests/test_fullsize_parity_gpu.py)."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", f"fullsize_{workload}.npz")
+    fx = np.load(path, allow_pickle=False)
+    N, E = prob.mesh.num_nodes, prob.mesh.num_elements
+    mesh_ok = ((N, E) == (int(fx["num_nodes"]), int(fx["num_elements"]))
+               and float(np.sum(prob.xy_flat * np.arange(1, 2 * N + 1) % 7.0)) == float(fx["xy_checksum"])
+               and int(np.sum(prob.conn_flat.astype(np.int64) * (np.arange(3 * E) % 11 + 1))) == int(fx["conn_checksum"]))
+    rule_ok = stop == "rel" and tol == float(fx["rel_tol"])
+    rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+    iu, ie = fx["dof_idx"], fx["elem_idx"]
+    slack = 0 if "1 thread" in str(fx["solver"]) else max(2, int(fx["iterations"]) // 1000)
+    d = {"fixture": os.path.relpath(path, ROOT), "oracle_iterations": int(fx["iterations"]), "iterations": int(iterations),
+         "mesh_is_the_fixtures": bool(mesh_ok), "stop_rule_is_the_fixtures": bool(rule_ok),
+         "rel_l2_u_sampled": rel(u[iu], fx["u_at"]),
+         "u_norm_rel_diff": abs(float(np.linalg.norm(u)) - float(fx["u_norm"])) / float(fx["u_norm"]),
+         "f_sampled_max_over_reaction_norm": float(np.abs(f[iu] - fx["f_at"]).max() / float(fx["f_known_norm"])),
+         "rel_l2_stress_sampled": rel(stress[ie], fx["stress_at"]), "bars": {"u": 1e-8, "f": 1e-7, "stress": 1e-7}}
+    d["ok"] = bool(mesh_ok and rule_ok and abs(d["iterations"] - d["oracle_iterations"]) <= slack
+                   and d["rel_l2_u_sampled"] <= 1e-8 and d["u_norm_rel_diff"] <= 1e-8
+                   and d["f_sampled_max_over_reaction_norm"] <= 1e-7 and d["rel_l2_stress_sampled"] <= 1e-7)
+    return d
 
 
 def kernel_line(kernel, nbytes, formula, ms_per_launch, pmc):
@@ -132,7 +216,8 @@ def kernel_line(kernel, nbytes, formula, ms_per_launch, pmc):
          "working_set_fits_infinity_cache": bool(nbytes < INFINITY_CACHE_BYTES)}
     if pmc and "hbm_bytes_per_launch" in pmc:
         d["traffic"] = pmc["hbm_bytes_per_launch"]
-        d["traffic_source"] = "profiles/r02_pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
+        d["traffic_source"] = "profiles/pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
+        d["traffic_stale"] = bool(pmc["stale"])  # true: counters of another build of the kernels than the one timed
     return d
 
 
@@ -150,7 +235,7 @@ def roofline_onchip(E, N, iters, ms_cg, pmc, tile):
     """k_cg_persist keeps the CG state in registers and LDS: HBM only sees the per-iteration exchange, so an HBM roof
     says nothing about it.  Its largest counted resource is fp64 vector issue (PMC: SQ_ACTIVE_INST_VALU), so it is
     priced against the fp64 vector peak with the ALGORITHMIC flops of the iterations it ran; the counted utilisations
-    of every resource (separate rocprofv3 --pmc passes, profiles/r02_pmc_summary.json) ride along."""
+    of every resource (separate rocprofv3 --pmc passes, profiles/pmc_summary.json) ride along."""
     flops = flops_iteration(E, N) * iters
     tf = flops / (ms_cg * 1e-3) / 1e12
     d = {"kernel": "k_cg_persist<%d> (the whole CG solve in ONE launch: state resident in registers and LDS, grid-wide "
@@ -163,10 +248,12 @@ def roofline_onchip(E, N, iters, ms_cg, pmc, tile):
     if pmc:
         t_it = ms_cg * 1e-3 / max(iters, 1)
         d["traffic"] = pmc["hbm_bytes_setup"] + pmc["hbm_bytes_per_iteration"] * iters
-        d["traffic_source"] = "profiles/r02_pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE; runs of two lengths)"
-        d["counted"] = dict(pmc.get("utilisation", {}))
-        d["counted"]["hbm_frac_live"] = pmc["hbm_bytes_per_iteration"] / t_it / 1e9 / HBM_PEAK_GBS
-        d["counted"]["source"] = "profiles/r02_pmc_counters.csv, per CG iteration (difference of two run lengths)"
+        d["traffic_source"] = "profiles/pmc_summary.json (2*FETCH_SIZE + WRITE_SIZE; runs of two lengths)"
+        d["traffic_stale"] = bool(pmc["stale"])
+        if not pmc["stale"]:  # utilisations of another build say nothing about this one: dropped, not quoted
+            d["counted"] = dict(pmc.get("utilisation", {}))
+            d["counted"]["hbm_frac_live"] = pmc["hbm_bytes_per_iteration"] / t_it / 1e9 / HBM_PEAK_GBS
+            d["counted"]["source"] = "profiles/pmc_summary.json, per CG iteration (difference of two run lengths)"
     return d
 
 
@@ -194,6 +281,21 @@ def hbm_resident_leg(device, reps):
             "seconds": time.perf_counter() - t0}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` started bare: run N ranks of this same command line under torch.distributed.run as a
+    fresh CHILD process (this parent has made no GPU call and never will), stdout/stderr inherited so that rank 0's
+    single JSON line is what the caller reads; returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:  # a free port for the rendezvous on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,6 +304,7 @@ def main():
     ap.add_argument("--workload", default="hole1m")
     ap.add_argument("--tol", type=float, default=1e-8)
     ap.add_argument("--stop", default="rel", choices=["rel", "rnorm", "rnorm_sq"])
+    ap.add_argument("--max-iter", type=int, default=0, help="CG iteration cap (0: the reference's MAX_CG_ITER = 1e7)")
     ap.add_argument("--tile", type=int, default=0, help="0: library default (512 for >= 262144 nodes, else 256)")
     ap.add_argument("--check-every", type=int, default=64)
     ap.add_argument("--no-graph", action="store_true")
@@ -221,6 +324,8 @@ def main():
                          "--partition strong)")
     ap.add_argument("--cpu-sample-iters", type=int, default=1500,
                     help="CG iterations of the 1-thread CPU sample (default ~11 s at 1M triangles; x4 for the OpenMP leg)")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the all-cores CPU leg (default: every core this process may use, usable_cores())")
     ap.add_argument("--op-reps", type=int, default=400)
     ap.add_argument("--rehearse-dist", action="store_true",
                     help="world size 1 only: still create the nccl process group and the RCCL communicator and run "
@@ -233,7 +338,15 @@ def main():
     ap.add_argument("--share-gpu", action="store_true",
                     help="REHEARSAL of the N > 1 code path on a one-GPU box: every rank drives GPU 0 and the collectives "
                          "go through gloo (host callback) instead of RCCL; the printed line is marked, it is no result")
+    ap.add_argument("--check-fixture", action="store_true",
+                    help="compare the returned solution on EVERY rank with the oracle's sampled solution of this workload "
+                         "at BASELINE size (tests/golden/fullsize_<workload>.npz: iteration count, u / f / stress at 4096 "
+                         "positions; needs --partition strong at N > 1, --stop rel and the fixture's tolerance); the line "
+                         "carries `fixture_parity`, exit code 6 on a miss")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch  # first: libmagnetite_hip.so then shares torch's HIP runtime and RCCL (same SONAMEs)
     import torch.distributed as dist
@@ -268,7 +381,7 @@ def main():
 
     ctx = Context(device=local_rank, stop_mode=stop_mode, tol=args.tol, tile_nodes=args.tile,
                   check_every=args.check_every, use_graph=0 if args.no_graph else 1, cg_variant=args.cg_variant,
-                  precision=1 if args.precision == "fp32" else 0)
+                  precision=1 if args.precision == "fp32" else 0, **({"max_iter": args.max_iter} if args.max_iter else {}))
     if use_dist and args.share_gpu:
         def host_allreduce(arr):
             dist.all_reduce(torch.from_numpy(arr))
@@ -276,7 +389,10 @@ def main():
     elif use_dist:
         ctx.init_rccl_from_torch(dist, rank, world)
     shm = None
-    exchange, autotune = ("RCCL all-reduce per iteration" if world > 1 else None), None
+    exchange, autotune = None, None
+    if world > 1:  # what carries the per-iteration all-reduce: RCCL on the library's stream, or (--share-gpu) gloo on the host
+        exchange = ("all-reduce per iteration through the host callback (gloo; --share-gpu rehearsal)" if args.share_gpu
+                    else "RCCL all-reduce per iteration")
     cpu_or_gpu = "cpu" if args.share_gpu else "cuda"
 
     def all_agree(ok):
@@ -407,6 +523,16 @@ def main():
     verify_ok = bool(verify <= verify_bar) if st["converged"] else None
     if use_dist:
         verify_ok = all_agree(verify_ok is not False)
+    parity = None
+    if args.check_fixture:
+        if world > 1 and args.partition != "strong":
+            raise SystemExit("--check-fixture needs the workload at its BASELINE size: --partition strong")
+        _, f_out, s_out = ctx.download()
+        parity = fixture_parity(args.workload, prob, u, f_out, s_out, st["iterations"], args.stop, args.tol)
+        parity["ok_on_every_rank"] = all_agree(parity["ok"]) if use_dist else parity["ok"]
+        if not parity["ok"]:
+            print(f"rank {rank}: fixture parity missed: {json.dumps(parity)}", file=sys.stderr, flush=True)
+    capped = not st["converged"]  # MAG_TERM_MAX_ITERS (or a breakdown): a normal return of the library, not a bench result
     comm = ctx.comm_info()
     fallback = bool(st["persist_timeout"])  # the on-chip kernel was chosen, gave up at its grid barrier, streaming redid it
 
@@ -433,9 +559,13 @@ def main():
                            load_pmc(f"{tile_key}:spmv"))
         asm_ms = st["ms_element"] + st["ms_assemble"] + st["ms_bc"]
         out = {
-            "metric": "elements/sec assembly + CG iters/sec (achieved HBM GB/s), 1M-tri mesh",
+            # BASELINE.json's metric; quoted on the 1M-triangle mesh, other workloads say which mesh they ran
+            "metric": "elements/sec assembly + CG iters/sec (achieved HBM GB/s), " +
+                      ("1M-tri mesh" if args.workload == "hole1m" else f"{args.workload} mesh"),
             "value": E * args.steps / elapsed, "unit": "elements/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            # N = 1 is the base point of the series the driver runs with these flags (weak: every added GPU adds one
+            # copy of the workload's mesh; strong: the same mesh split over more GPUs)
             "higher_is_better": True, "scaling": args.partition, "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "f64",
             "data": "synthetic",
@@ -452,6 +582,11 @@ def main():
             "verify": {"rel_true_residual": verify, "bar": verify_bar, "ok_on_every_rank": verify_ok,
                        "what": "|f - K u| on the unknown DOFs / |b|, K applied matrix-free to the whole mesh"},
             "cg_iterations": iters, "cg_converged": int(st["converged"]), "cg_final_cost": st["final_cost"],
+            "cg_termination": {0: "none", 1: "target_cost", 2: "max_iters", 3: "breakdown"}.get(int(st["termination"])),
+            "cg_best_iteration": int(st["best_iteration"]),
+            # stopped at the iteration cap (solver.rs:149-176 returns Ok(best_param) there, and so does mag_run): the
+            # steps then measured unconverged solves, each running the CG twice (best_param rerun) -- not a result
+            "capped": bool(capped), "fixture_parity": parity,
             "cg_iters_per_sec": iters / (st["ms_cg"] * 1e-3) if st["ms_cg"] > 0 else None,
             # the SURVEY 8(d) figure of the metric's name: bytes an UNFUSED iteration streams / time per iteration.  An
             # equivalent rate, not HBM utilisation (the fused and on-chip kernels move far less): see roofline
@@ -473,9 +608,9 @@ def main():
             ctx.close()  # its buffers are not needed any more; the 16M leg allocates ~5 GB of its own
             out["hbm_resident"] = hbm_resident_leg(local_rank, args.op_reps)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(prob, iters, stop_mode, args.tol, args.cpu_sample_iters)
+            out["cpu_baseline"] = cpu_baseline(prob, iters, stop_mode, args.tol, args.cpu_sample_iters, args.cpu_threads)
             out["cpu_baseline"]["cores_available"] = os.cpu_count()
-            rec = os.path.join(ROOT, "profiles", "r02_cpu_baseline.json")
+            rec = CPU_RECORD if os.path.exists(CPU_RECORD) else os.path.join(ROOT, "profiles", "r02_cpu_baseline.json")
             if os.path.exists(rec):  # scripts/cpu_baseline_record.py: BASELINE.md section 2 items 1-3, timed once
                 rj = json.load(open(rec))
                 out["cpu_baseline"]["config1_dense_s"] = rj.get("config1_dense_s")
@@ -484,7 +619,7 @@ def main():
                     out["cpu_baseline"]["config3_full_solve_s"] = c3["assembly_and_bc_s"] + c3["cg_s"]
                     out["cpu_baseline"]["config3_full_solve_elements_per_s"] = c3["elements_per_s"]
                 out["cpu_baseline"]["record_host"] = rj.get("host")
-                out["cpu_baseline"]["record"] = "profiles/r02_cpu_baseline.json"
+                out["cpu_baseline"]["record"] = os.path.relpath(rec, ROOT)
         else:
             out["cpu_baseline"] = None
         if args.share_gpu:
@@ -503,6 +638,15 @@ def main():
             shm.unlink()
     if use_dist:
         dist.destroy_process_group()
+    if capped:
+        print(f"bench.py: the CG stopped without reaching its target (termination {int(st['termination'])}, "
+              f"{int(st['iterations'])} iterations, best iterate {int(st['best_iteration'])}): the line is marked "
+              f"\"capped\": true and is not a result", file=sys.stderr, flush=True)
+        sys.exit(5)
+    if parity is not None and not parity.get("ok_on_every_rank"):
+        print("bench.py: the returned solution misses the oracle fixture on some rank (fixture_parity)", file=sys.stderr,
+              flush=True)
+        sys.exit(6)
     if verify_ok is False:
         print(f"bench.py: the returned solution does not satisfy K u = f (relative true residual {verify:.3e})",
               file=sys.stderr, flush=True)

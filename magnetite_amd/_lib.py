@@ -66,6 +66,30 @@ class Stats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+HASHED_SOURCES = ("persist.hip", "cg.hip", "cg_device.h", "exact.hip", "symbolic.hip", "kernels.h")
+
+
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources as they are in the tree now -- the digest csrc/Makefile
+    writes next to the library when it links it."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in HASHED_SOURCES:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def built_source_hash():
+    """The digest recorded when the loaded library was linked (None for a library built by other means)."""
+    path = os.path.splitext(SO_PATH)[0] + ".srchash"
+    try:
+        with open(path) as f:
+            return f.read().strip() or None
+    except OSError:
+        return None
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
 
 

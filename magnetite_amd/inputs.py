@@ -15,7 +15,9 @@ from .solver import MagnetiteError, ModelMetadata
 
 
 def load_input_file(path):
-    """mesher.rs:713-760"""
+    """mesher.rs:713-760: the reference's checks in the reference's order, with its messages verbatim (the
+    `boundary_conditions` one says "in metadata section" there too, mesher.rs:738-741; after "Error in input file json: "
+    comes the json parser's own text -- the `json` crate's there, Python's here)."""
     try:
         with open(path) as f:
             text = f.read()
@@ -24,10 +26,15 @@ def load_input_file(path):
     try:
         doc = json.loads(text)
     except json.JSONDecodeError as err:
-        raise MagnetiteError("Input", f"Invalid json in input file: {err}")
-    for key in ("metadata", "boundary_conditions"):
-        if key not in doc:
-            raise MagnetiteError("Input", f"Input json missing {key} field")
+        raise MagnetiteError("Input", f"Error in input file json: {err}")
+    has = lambda obj, key: isinstance(obj, dict) and key in obj  # JsonValue::has_key is false on non-objects
+    if not has(doc, "metadata"):
+        raise MagnetiteError("Input", "Input json missing metadata field")
+    if not has(doc, "boundary_conditions"):
+        raise MagnetiteError("Input", "Input json missing boundary_conditions field in metadata section")
+    for key in ("part_thickness", "material_elasticity", "poisson_ratio"):
+        if not has(doc["metadata"], key):
+            raise MagnetiteError("Input", f"Input json missing {key} field in metadata section")
     return doc
 
 

@@ -68,6 +68,10 @@ def lib():
         L.orc_assemble_sparse.argtypes = [C.c_int64, C.c_int64, dp, ip, C.c_double, C.c_double, C.c_double]
         L.orc_reduce_system.restype = C.c_void_p
         L.orc_reduce_system.argtypes = [C.c_void_p, bp, dp, dp, dp]
+        L.orc_assemble_sparse_omp.restype = C.c_void_p
+        L.orc_assemble_sparse_omp.argtypes = L.orc_assemble_sparse.argtypes
+        L.orc_reduce_system_omp.restype = C.c_void_p
+        L.orc_reduce_system_omp.argtypes = L.orc_reduce_system.argtypes
         run_args = [C.c_int64, C.c_int64, dp, ip, bp, dp, dp, C.c_double, C.c_double, C.c_double,
                     C.c_int, C.c_double, C.c_int64, dp, dp, dp, C.POINTER(Stats), dp, C.c_int64]
         L.orc_run_dense.argtypes = run_args
@@ -181,18 +185,32 @@ def sparsify_dense(A):
     return Csr(lib().orc_sparsify_dense(A.shape[0], _d(A)))
 
 
-def assemble_sparse(xy, conn, nu, youngs, thickness):
+def set_threads(threads):
+    """OpenMP thread count of the all-cores variants (None keeps OMP_NUM_THREADS / the runtime default)."""
+    if threads:
+        os.environ["OMP_NUM_THREADS"] = str(int(threads))
+        try:
+            C.CDLL("libgomp.so.1").omp_set_num_threads(int(threads))
+        except OSError:
+            pass
+
+
+def assemble_sparse(xy, conn, nu, youngs, thickness, threads=None):
+    """threads=None: the serial restatement; threads=k: the OpenMP variant (rows are independent), same bits."""
     xy, conn = _prep(xy, conn)
-    return Csr(lib().orc_assemble_sparse(xy.size // 2, conn.size // 3, _d(xy), _i(conn), float(nu),
-                                         float(youngs), float(thickness)))
+    set_threads(threads)
+    fn = lib().orc_assemble_sparse_omp if threads else lib().orc_assemble_sparse
+    return Csr(fn(xy.size // 2, conn.size // 3, _d(xy), _i(conn), float(nu), float(youngs), float(thickness)))
 
 
-def reduce_system(K, u_known, u_in, f_in):
+def reduce_system(K, u_known, u_in, f_in, threads=None):
     u_known = np.ascontiguousarray(u_known, dtype=np.uint8)
     nf = int(K.n - u_known.sum())
     b = np.zeros(max(nf, 1))
-    h = lib().orc_reduce_system(K._h, _b(u_known), _d(np.ascontiguousarray(u_in, dtype=np.float64)),
-                                _d(np.ascontiguousarray(f_in, dtype=np.float64)), _d(b))
+    set_threads(threads)
+    fn = lib().orc_reduce_system_omp if threads else lib().orc_reduce_system
+    h = fn(K._h, _b(u_known), _d(np.ascontiguousarray(u_in, dtype=np.float64)),
+           _d(np.ascontiguousarray(f_in, dtype=np.float64)), _d(b))
     return Csr(h), b[:nf]
 
 
@@ -207,12 +225,7 @@ def cg(A, b, stop_mode=STOP_RNORM, tol=TARGET_CG_COST, max_iter=MAX_CG_ITER, his
 
 def cg_parallel(A, b, stop_mode=STOP_RNORM, tol=TARGET_CG_COST, max_iter=MAX_CG_ITER, threads=None):
     """All-cores variant (OpenMP).  threads=None keeps OMP_NUM_THREADS / the runtime default."""
-    if threads:
-        os.environ["OMP_NUM_THREADS"] = str(int(threads))
-        try:
-            C.CDLL("libgomp.so.1").omp_set_num_threads(int(threads))
-        except OSError:
-            pass
+    set_threads(threads)
     b = np.ascontiguousarray(b, dtype=np.float64)
     x = np.zeros(max(A.n, 1))
     cost = C.c_double(0.0)

@@ -589,6 +589,160 @@ orc_csr *orc_assemble_sparse(int64_t N, int64_t E, const double *xy, const int32
     return m;
 }
 
+/* All-cores variant of orc_assemble_sparse (bench.py's cpu_baseline.all_cores leg).
+ * Rows of K are independent: the reference couples them only through shared elements (solver.rs:304-322), so a
+ * thread owns a range of row NODES and, per node, walks the node's incident elements in ascending element order --
+ * the order in which solver.rs:299-325 adds into that row -- adding rows 2a, 2a+1 of K_e (a = the node's corner in
+ * the element).  Same pattern, same '+=' order per entry: bit-identical to the serial path
+ * (tests/test_oracle_paths.py).  An element is evaluated once per corner (3x the flops of the serial loop). */
+static int cmp_i32(const void *a, const void *b)
+{
+    const int32_t x = *(const int32_t *)a, y = *(const int32_t *)b;
+    return (x > y) - (x < y);
+}
+
+orc_csr *orc_assemble_sparse_omp(int64_t N, int64_t E, const double *xy, const int32_t *conn, double nu,
+                                 double youngs, double thickness)
+{
+    /* incidence lists: (element, corner) per node, ascending element (counting sort, serial O(E): a few ms) */
+    int64_t *iptr = (int64_t *)calloc((size_t)N + 2, sizeof(int64_t));
+    for (int64_t k = 0; k < 3 * E; ++k) iptr[conn[k] + 1]++;
+    for (int64_t i = 0; i < N; ++i) iptr[i + 1] += iptr[i];
+    int64_t *fill = (int64_t *)malloc(sizeof(int64_t) * ((size_t)N + 1));
+    memcpy(fill, iptr, sizeof(int64_t) * ((size_t)N + 1));
+    int64_t *inc = (int64_t *)malloc(sizeof(int64_t) * (size_t)(3 * E + 1));
+    for (int64_t k = 0; k < 3 * E; ++k) inc[fill[conn[k]]++] = k; /* k = 3e + corner, ascending in e per node */
+    free(fill);
+    /* pattern: distinct nodes of the row node's incident elements, ascending */
+    int64_t *bptr = (int64_t *)calloc((size_t)N + 2, sizeof(int64_t));
+#pragma omp parallel
+    {
+        int32_t *tmp = NULL;
+        int64_t cap = 0;
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < N; ++i) {
+            const int64_t d = iptr[i + 1] - iptr[i];
+            if (3 * d > cap) { cap = 3 * d + 64; tmp = (int32_t *)realloc(tmp, sizeof(int32_t) * (size_t)cap); }
+            int64_t m = 0;
+            for (int64_t q = iptr[i]; q < iptr[i + 1]; ++q) {
+                const int64_t e = inc[q] / 3;
+                for (int c = 0; c < 3; ++c) tmp[m++] = conn[3 * e + c];
+            }
+            qsort(tmp, (size_t)m, sizeof(int32_t), cmp_i32);
+            int64_t u = 0;
+            for (int64_t q = 0; q < m; ++q)
+                if (q == 0 || tmp[q] != tmp[q - 1]) u++;
+            bptr[i + 1] = u;
+        }
+        free(tmp);
+    }
+    for (int64_t i = 0; i < N; ++i) bptr[i + 1] += bptr[i];
+    const int64_t nb = bptr[N];
+    orc_csr *m = (orc_csr *)calloc(1, sizeof(orc_csr));
+    m->n = 2 * N;
+    m->nnz = 4 * nb;
+    m->rowptr = (int64_t *)calloc((size_t)m->n + 1, sizeof(int64_t));
+    m->col = (int32_t *)malloc(sizeof(int32_t) * (size_t)(m->nnz ? m->nnz : 1));
+    m->val = (double *)malloc(sizeof(double) * (size_t)(m->nnz ? m->nnz : 1));
+    m->rowptr[m->n] = m->nnz;
+#pragma omp parallel
+    {
+        int32_t *tmp = NULL;
+        int64_t cap = 0;
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < N; ++i) {
+            const int64_t d = iptr[i + 1] - iptr[i], cnt = bptr[i + 1] - bptr[i];
+            if (3 * d > cap) { cap = 3 * d + 64; tmp = (int32_t *)realloc(tmp, sizeof(int32_t) * (size_t)cap); }
+            int64_t mm = 0;
+            for (int64_t q = iptr[i]; q < iptr[i + 1]; ++q) {
+                const int64_t e = inc[q] / 3;
+                for (int c = 0; c < 3; ++c) tmp[mm++] = conn[3 * e + c];
+            }
+            qsort(tmp, (size_t)mm, sizeof(int32_t), cmp_i32);
+            int64_t u = 0;
+            for (int64_t q = 0; q < mm; ++q)
+                if (q == 0 || tmp[q] != tmp[q - 1]) tmp[u++] = tmp[q];
+            m->rowptr[2 * i] = 4 * bptr[i];
+            m->rowptr[2 * i + 1] = 4 * bptr[i] + 2 * cnt;
+            int32_t *c0 = m->col + 4 * bptr[i], *c1 = c0 + 2 * cnt;
+            double *r0 = m->val + 4 * bptr[i], *r1 = r0 + 2 * cnt;
+            for (int64_t k = 0; k < cnt; ++k) {
+                c0[2 * k] = c1[2 * k] = 2 * tmp[k];
+                c0[2 * k + 1] = c1[2 * k + 1] = 2 * tmp[k] + 1;
+                r0[2 * k] = r0[2 * k + 1] = r1[2 * k] = r1[2 * k + 1] = 0.0;
+            }
+            for (int64_t q = iptr[i]; q < iptr[i + 1]; ++q) { /* ascending element order: solver.rs:299-325 */
+                const int64_t e = inc[q] / 3;
+                const int lr = (int)(inc[q] % 3);
+                double k[36];
+                orc_element_stiffness(xy, conn + 3 * e, nu, youngs, thickness, k);
+                for (int lc = 0; lc < 3; ++lc) {
+                    const int32_t j = conn[3 * e + lc];
+                    int64_t lo = 0, hi = cnt - 1;
+                    while (lo < hi) {
+                        const int64_t mid = (lo + hi) / 2;
+                        if (tmp[mid] < j) lo = mid + 1; else hi = mid;
+                    }
+                    r0[2 * lo] += k[(2 * lr) * 6 + 2 * lc];
+                    r0[2 * lo + 1] += k[(2 * lr) * 6 + 2 * lc + 1];
+                    r1[2 * lo] += k[(2 * lr + 1) * 6 + 2 * lc];
+                    r1[2 * lo + 1] += k[(2 * lr + 1) * 6 + 2 * lc + 1];
+                }
+            }
+        }
+        free(tmp);
+    }
+    free(inc);
+    free(iptr);
+    free(bptr);
+    return m;
+}
+
+/* All-cores variant of orc_reduce_system: rows are independent; count -> prefix sum -> fill. */
+orc_csr *orc_reduce_system_omp(const orc_csr *K, const uint8_t *u_known, const double *u_in,
+                               const double *f_in, double *b /* n_free */)
+{
+    const int64_t n = K->n;
+    int32_t *fidx = (int32_t *)malloc(sizeof(int32_t) * ((size_t)n + 1));
+    int64_t nf = 0;
+    for (int64_t i = 0; i < n; ++i) fidx[i] = u_known[i] ? -1 : (int32_t)nf++;
+    orc_csr *m = (orc_csr *)calloc(1, sizeof(orc_csr));
+    m->n = nf;
+    m->rowptr = (int64_t *)calloc((size_t)nf + 2, sizeof(int64_t));
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < n; ++r) {
+        if (u_known[r]) continue;
+        int64_t c = 0;
+        for (int64_t p = K->rowptr[r]; p < K->rowptr[r + 1]; ++p)
+            c += (!u_known[K->col[p]] && K->val[p] != 0.0);
+        m->rowptr[fidx[r] + 1] = c;
+    }
+    for (int64_t i = 0; i < nf; ++i) m->rowptr[i + 1] += m->rowptr[i];
+    const int64_t nnz = m->rowptr[nf];
+    m->nnz = nnz;
+    m->col = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nnz ? nnz : 1));
+    m->val = (double *)malloc(sizeof(double) * (size_t)(nnz ? nnz : 1));
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < n; ++r) {
+        if (u_known[r]) continue;
+        const int64_t lr = fidx[r];
+        int64_t q = m->rowptr[lr];
+        double s = 0.0;
+        for (int64_t p = K->rowptr[r]; p < K->rowptr[r + 1]; ++p) {
+            const int32_t c = K->col[p];
+            if (u_known[c])
+                s += (K->val[p] * u_in[c]) * -1.0;
+            else if (K->val[p] != 0.0) {
+                m->col[q] = fidx[c];
+                m->val[q++] = K->val[p];
+            }
+        }
+        b[lr] = s + f_in[r];
+    }
+    free(fidx);
+    return m;
+}
+
 /* solver.rs:365-404,427-432,123-137 on the CSR of K: K_ff in compact unknown
  * numbering with exact zeros dropped, and b = sum_known -(K*u) + f (ascending
  * column; skipped structural zeros contribute exact +-0). */

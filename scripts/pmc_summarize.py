@@ -1,5 +1,10 @@
 """Aggregate the rocprofv3 --pmc passes of scripts/pmc_passes.sh: mean counter value per launch of the CG kernels ->
-profiles/r02_pmc_counters.csv, and what bench.py reads -> profiles/r02_pmc_summary.json:
+profiles/<tag>_pmc_counters.csv, and what bench.py reads -> profiles/pmc_summary.json (+ a copy named
+profiles/<tag>_pmc_summary.json for the round's record).  The summary carries `_meta.source_hash`, the digest of the kernel
+sources the profiled library was linked from (magnetite_amd/libmagnetite_hip.srchash, written by csrc/Makefile):
+bench.py compares it with the digest of the library IT loads and marks the counters stale on a mismatch.
+
+      python scripts/pmc_summarize.py <dir of the passes> <tag>
 
   HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) KB, as MI355X_MICROARCH.md (HBM section) prescribes for gfx950: FETCH_SIZE
   reports half of a wide coalesced stream, WRITE_SIZE is exact for 16-byte-per-lane stores.
@@ -22,7 +27,7 @@ import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "gpurun_out", "pmc")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
 SIMDS, CUS = 1024, 256
 acc = collections.defaultdict(lambda: collections.defaultdict(list))  # (workload, kernel, iters) -> counter -> values
 for path in glob.glob(os.path.join(src, "*_v*_it*_pass*", "**", "*counter_collection.csv"), recursive=True):
@@ -96,5 +101,10 @@ for wl in sorted({w for (w, k, i) in acc}):
         # times); never below zero
         "hbm_bytes_setup": max(0.0, b0 - per_it * i0), "waves": waves, "utilisation": util,
         "counters_per_iteration": per, "note": note + "; one launch per solve, two run lengths"}
-json.dump(summary, open(os.path.join(root, "profiles", f"{tag}_pmc_summary.json"), "w"), indent=1)
+sys.path.insert(0, root)
+from magnetite_amd import _lib  # noqa: E402  (no GPU call: only reads the digest next to the library)
+summary["_meta"] = {"source_hash": _lib.built_source_hash(), "hashed_sources": list(_lib.HASHED_SOURCES), "tag": tag,
+                    "passes": os.path.relpath(src, root)}
+for name in (f"{tag}_pmc_summary.json", "pmc_summary.json"):
+    json.dump(summary, open(os.path.join(root, "profiles", name), "w"), indent=1)
 print(json.dumps(summary, indent=1))

@@ -67,6 +67,25 @@ def test_input_errors_exit_code_and_message(exe, tensile_files, tmp_path):
     assert "Received error: Input error: Boundary 'load' is over-constrained in x-axis" in r.stderr
     r = subprocess.run([exe, str(tmp_path / "nope.json"), str(d / "geom.msh"), "--dry-run"], capture_output=True, text=True)
     assert r.returncode == 1 and "Input error: Unable to open input file" in r.stderr
+    # load_input_file's key checks, messages verbatim and in the reference's order (mesher.rs:733-755)
+    for mutate, msg in ((lambda b: b.pop("metadata"), "Input json missing metadata field"),
+                        (lambda b: b.pop("boundary_conditions"),
+                         "Input json missing boundary_conditions field in metadata section"),
+                        (lambda b: b["metadata"].pop("part_thickness"),
+                         "Input json missing part_thickness field in metadata section"),
+                        (lambda b: b["metadata"].pop("material_elasticity"),
+                         "Input json missing material_elasticity field in metadata section"),
+                        (lambda b: b["metadata"].pop("poisson_ratio"),
+                         "Input json missing poisson_ratio field in metadata section")):
+        bad = json.loads(json.dumps(TENSILE_JSON))
+        mutate(bad)
+        (tmp_path / "bad.json").write_text(json.dumps(bad))
+        r = subprocess.run([exe, str(tmp_path / "bad.json"), str(d / "geom.msh"), "--dry-run"], capture_output=True,
+                           text=True)
+        assert r.returncode == 1 and r.stderr.strip().endswith("Received error: Input error: " + msg), r.stderr
+    (tmp_path / "bad.json").write_text('{"metadata": ')
+    r = subprocess.run([exe, str(tmp_path / "bad.json"), str(d / "geom.msh"), "--dry-run"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Received error: Input error: Error in input file json: " in r.stderr
 
 
 @pytest.mark.gpu

@@ -68,8 +68,19 @@ def test_input_json_tensile_example(tmp_path):
 
 
 @pytest.mark.parametrize("mutate,msg", [
-    (lambda d: d["metadata"].pop("material_elasticity"), "Input json missing material elasticity"),
-    (lambda d: d["metadata"].pop("poisson_ratio"), "Input json missing poisson ratio"),
+    # load_input_file (mesher.rs:733-755), verbatim and in the reference's order
+    (lambda d: d.pop("metadata"), "Input json missing metadata field$"),
+    (lambda d: d.pop("boundary_conditions"), "Input json missing boundary_conditions field in metadata section$"),
+    (lambda d: d["metadata"].pop("part_thickness"), "Input json missing part_thickness field in metadata section$"),
+    (lambda d: d["metadata"].pop("material_elasticity"), "Input json missing material_elasticity field in metadata section$"),
+    (lambda d: d["metadata"].pop("poisson_ratio"), "Input json missing poisson_ratio field in metadata section$"),
+    (lambda d: (d["metadata"].pop("poisson_ratio"), d["metadata"].pop("part_thickness")),
+     "Input json missing part_thickness field in metadata section$"),          # first failing check wins
+    # parse_input_metadata (mesher.rs:769-808): present but not a number
+    (lambda d: d["metadata"].update(material_elasticity="stiff"), "Input json missing material elasticity$"),
+    (lambda d: d["metadata"].update(poisson_ratio=None), "Input json missing poisson ratio$"),
+    (lambda d: d["metadata"].pop("characteristic_length_min"), "Input json missing minimum characteristic length$"),
+    (lambda d: d["metadata"].pop("characteristic_length_max"), "Input json missing maximum characteristic length$"),
     (lambda d: d["boundary_conditions"]["load"].pop("region"), "Boundary rule load is missing region field"),
     (lambda d: d["boundary_conditions"]["load"].pop("targets"), "Boundary rule load is missing target field"),
     (lambda d: d["boundary_conditions"]["load"]["targets"].update(fx=1.0), "over-constrained in x-axis"),
@@ -85,8 +96,11 @@ def test_input_json_errors(tmp_path, mutate, msg):
         doc = load_input_file(str(path))
         parse_input_metadata(doc)
         parse_boundary_rules(doc)
-    with pytest.raises(MagnetiteError, match="Unable to open input file"):
+    with pytest.raises(MagnetiteError, match="^Input error: Unable to open input file " + str(tmp_path / "missing.json") + "$"):
         load_input_file(str(tmp_path / "missing.json"))
+    (tmp_path / "broken.json").write_text('{"metadata": ')
+    with pytest.raises(MagnetiteError, match="^Input error: Error in input file json: "):
+        load_input_file(str(tmp_path / "broken.json"))
 
 
 MSH_SAMPLE = """$MeshFormat

@@ -125,6 +125,22 @@ def test_parallel_cg_variant_agrees(built):
     assert abs(it - itp) <= 3 and cost <= 1e-4 and rel(xp, x) <= 1e-9
 
 
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("threads", [1, 3])
+def test_openmp_assembly_is_bit_identical_to_the_serial_restatement(built, name, threads):
+    """the all-cores CPU baseline (bench.py cpu_baseline.all_cores): rows of K are independent, each row adds its
+    elements in ascending element order like solver.rs:299-325 -- same pattern, same bits, for K, K_ff and b"""
+    p = CASES[name]()
+    args = (p.xy_flat, p.conn_flat, p.poisson_ratio, p.youngs_modulus, p.part_thickness)
+    K, Kp = oracle.assemble_sparse(*args), oracle.assemble_sparse(*args, threads=threads)
+    A, b = oracle.reduce_system(K, p.u_known, p.u_in, p.f_in)
+    Ap, bp = oracle.reduce_system(Kp, p.u_known, p.u_in, p.f_in, threads=threads)
+    for x, y in ((K, Kp), (A, Ap)):
+        assert x.n == y.n and x.nnz == y.nnz
+        assert np.array_equal(x.rowptr, y.rowptr) and np.array_equal(x.col, y.col) and np.array_equal(x.val, y.val)
+    assert np.array_equal(b, bp)
+
+
 def test_clockwise_mesh_same_displacements_for_displacement_loading(built):
     """K -> -K and b -> -b when every element is reversed and all loads are prescribed displacements."""
     a = run(meshgen.config_fixed_left_pull_right(meshgen.plate(8)), "dense")

@@ -59,7 +59,7 @@ struct JsonParser {
     {
         while (i < s.size() && (s[i] == ' ' || s[i] == '\n' || s[i] == '\t' || s[i] == '\r')) ++i;
     }
-    [[noreturn]] void bad(const char *what) { die({MagnetiteError::Input, std::string("Invalid json in input file: ") + what}); }
+    [[noreturn]] void bad(const char *what) { die({MagnetiteError::Input, std::string("Error in input file json: ") + what}); }
     Json value()
     {
         ws();
@@ -341,8 +341,14 @@ int main(int argc, char **argv)
     const std::string text = slurp(input, MagnetiteError::Input, "Unable to open input file " + input);
     JsonParser jp(text);
     const Json doc = jp.value();
-    for (const char *k : {"metadata", "boundary_conditions"})
-        if (!doc.has(k)) die({MagnetiteError::Input, std::string("Input json missing ") + k + " field"});
+    // load_input_file's checks in its order, messages verbatim (mesher.rs:733-755; "in metadata section" for
+    // boundary_conditions is the reference's own wording)
+    if (!doc.has("metadata")) die({MagnetiteError::Input, "Input json missing metadata field"});
+    if (!doc.has("boundary_conditions"))
+        die({MagnetiteError::Input, "Input json missing boundary_conditions field in metadata section"});
+    for (const char *k : {"part_thickness", "material_elasticity", "poisson_ratio"})
+        if (!doc.get("metadata")->has(k))
+            die({MagnetiteError::Input, std::string("Input json missing ") + k + " field in metadata section"});
     const ModelMetadata meta = parse_input_metadata(doc);
     std::vector<Node> nodes;
     std::vector<Element> elements;
