@@ -511,7 +511,7 @@ def main():
     # with several ranks each launch covers the tiles this rank owns (its per-GPU share)
     ms_op = ctx.time_operator(args.op_reps)   # the streaming CG iteration kernel (one launch per iteration)
     ms_spmv = ctx.time_spmv(args.op_reps)     # the plain matrix-free SpMV y = M K M v
-    u, _, _ = ctx.download()
+    u, f_out, s_out = ctx.download()
     # Self-check of the returned solution, independent of how it was produced and gathered: the true residual
     # f - K u on the unknown DOFs, with K applied matrix-free to the whole mesh by this rank alone, against |b|.  A
     # converged solve sits at about the stop tolerance; an exchange or gather that went wrong would not.
@@ -527,7 +527,6 @@ def main():
     if args.check_fixture:
         if world > 1 and args.partition != "strong":
             raise SystemExit("--check-fixture needs the workload at its BASELINE size: --partition strong")
-        _, f_out, s_out = ctx.download()
         parity = fixture_parity(args.workload, prob, u, f_out, s_out, st["iterations"], args.stop, args.tol)
         parity["ok_on_every_rank"] = all_agree(parity["ok"]) if use_dist else parity["ok"]
         if not parity["ok"]:
