@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MAG_ABI_VERSION 2
+#define MAG_ABI_VERSION 3 /* 3: mag_stats gained exchange_timeout, best_param_mismatch */
 
 /* solver.rs:17-19 */
 #define MAG_DOF 2
@@ -180,7 +180,16 @@ typedef struct mag_stats {
                                `iterations` unless the solve stopped at the iteration cap                            */
     int32_t termination;    /* enum mag_termination */
     int32_t persist_timeout; /* 1: the on-chip CG kernel gave up at its grid barrier in this run (not every workgroup was
-                               co-resident) and the streaming kernels redid the solve; the context streams from then on */
+                               co-resident) and the streaming kernels redid the solve; the context then streams for a
+                               number of solves (8, doubling after every further failure, at most 1024) before it tries
+                               the on-chip kernel again */
+    int32_t exchange_timeout; /* 1: several ranks, the inbox exchange of the streaming kernels gave up in this run and the
+                                 ranks redid the solve with one all-reduce per iteration; the context keeps the all-reduce
+                                 until its inboxes are created anew (mag_comm_inbox_create)                        */
+    int32_t best_param_mismatch; /* iteration cap only: the iterate of `best_iteration` is recovered by repeating the
+                                    solve up to that iteration; 1 when the repeat took another kernel or exchange than the
+                                    first pass, or its cost there is not the recorded best cost bit for bit --
+                                    `final_cost` is then the cost of the iterate actually returned                  */
 } mag_stats;
 
 /* ---- lifecycle ------------------------------------------------------- */

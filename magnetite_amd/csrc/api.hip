@@ -120,6 +120,9 @@ struct mag_ctx {
     bool pre = false;  // mag_options.preconditioner != 0
     // on-chip CG (persist.hip, k_cg_persist): the whole solve in one launch when every tile fits registers + LDS
     bool persist = false, persist_failed = false;
+    // after a grid-barrier timeout the context streams for `persist_retry_in` solves, then tries the on-chip kernel again;
+    // the wait doubles with every further failure (8 .. 1024 solves) and starts over after a success
+    int persist_backoff = 0, persist_retry_in = 0;
     int32_t persist_k = 0, persist_grid = 0, persist_maxh = 0, cg_kernel = 0;
     DevBuf qx, wg_part, psync, grec; // published-q granules, partial-record granules, timeout word, republished sums
     // multi-GPU on-chip CG: a window of host memory mapped by every rank (mag_comm_set_window)
@@ -135,11 +138,11 @@ struct mag_ctx {
     uint32_t solve_seq = 0;
     double best_cost = 0.0;   // argmin's best_param bookkeeping, as the CG phase that just ran reported it
     long long best_iter = 0;
-    bool persist_timed_out = false;
+    bool persist_timed_out = false, exchange_timed_out = false;
     // streaming kernels across GPUs: the per-iteration exchange through the device inboxes (k_stream_exchange) instead of
     // an all-reduce; si_failed: a wait ran out once, this context uses the all-reduce from then on
     bool si = false, si_failed = false;
-    uint32_t si_epoch = 0, si_tag_base = 0, si_spin = 1u << 20; // polls (~2 us each) before an exchange gives up
+    uint32_t si_tag_base = 0, si_spin = 1u << 20; // polls (~2 us each) before an exchange gives up
     int32_t exchange_kind = 0; // mag_stats.exchange of the last run // the on-chip kernel gave up at its grid barrier in this run (mag_stats.persist_timeout)
     int nsums() const { return pre ? 5 : 4; }
     DevBuf xy32, hxy32, rqp32a, rqp32b, x32; // fp32 leg (mag_options.precision = 1)
@@ -148,6 +151,8 @@ struct mag_ctx {
         void *ptrs[20];
         int64_t N;
         int32_t T, B, G, hist_len;
+        void *dptrs[12];  // distributed block (streaming kernels + k_stream_exchange): exchange buffer, slot tables, inboxes
+        int32_t d[12];    // ... and its scalars (all zero on one GPU)
     } gkey = {};
 
     // results (caller numbering)
@@ -949,12 +954,12 @@ int fused_block(mag_ctx *ctx, int G)
         const magk::FusedParams P = fused_params(ctx, i & 1);
         magk::fused_launch(P, ctx->B, ctx->fgrid, ctx->stream);
         if (ctx->dist && ctx->si) {
-            // the iteration's exchange through the device inboxes, in place on the buffer the launch just filled
-            ++ctx->si_epoch;
+            // the iteration's exchange through the device inboxes, in place on the buffer the launch just filled; its
+            // epoch and tag come from the launch counter in FusedState, so the pair is the same node in every replay
             magk::stream_exchange_launch(P.part_out, ctx->g_all, ctx->n_iface, ctx->comm.rank, ctx->comm.nranks, ctx->own0,
-                                         ctx->own1, (int32_t)(ctx->si_epoch & 1u), ctx->si_tag_base + ctx->si_epoch,
-                                         ctx->si_spin, ctx->iface.as<int32_t>(), ctx->iface_readers.as<uint8_t>(),
-                                         ctx->inbox_peer, ctx->fstate.as<magk::FusedState>(), ctx->stream);
+                                         ctx->own1, i & 1, ctx->si_spin, ctx->iface.as<int32_t>(),
+                                         ctx->iface_readers.as<uint8_t>(), ctx->inbox_peer,
+                                         ctx->fstate.as<magk::FusedState>(), ctx->stream);
         } else if (ctx->dist) {
             // the iteration's ONE collective, in place on the buffer the launch just filled:
             // [r.r, p.q, r.q, q.q partials, slot by slot | q on interface nodes (owner's value + zeros)]
@@ -1021,6 +1026,14 @@ int ensure_fused_graph(mag_ctx *ctx, int G)
     double mat[2] = {ctx->youngs * ctx->thick, ctx->nu};
     memcpy(&k.ptrs[18], &mat[0], 8);
     memcpy(&k.ptrs[19], &mat[1], 8);
+    if (ctx->dist) { // only the inbox exchange is captured (two kernels per iteration, no host work)
+        void *dp[] = {ctx->comm_f.p, ctx->own_qslot.p, ctx->halo_qslot.p, ctx->iface_readers.p};
+        for (int i = 0; i < 4; ++i) k.dptrs[i] = dp[i];
+        for (int r = 0; r < 8; ++r) k.dptrs[4 + r] = ctx->inbox_peer[r];
+        const int32_t dv[] = {1, ctx->g_all, ctx->n_iface, ctx->comm.rank, ctx->comm.nranks, ctx->own0, ctx->own1,
+                              ctx->t0, ctx->t1, (int32_t)ctx->si_spin, (int32_t)ctx->cwords, ctx->nsums()};
+        for (int i = 0; i < 12; ++i) k.d[i] = dv[i];
+    }
     if (ctx->graph && memcmp(&k, &ctx->gkey, sizeof k) == 0) return MAG_OK;
     if (ctx->graph) {
         (void)hipGraphExecDestroy(ctx->graph);
@@ -1063,7 +1076,6 @@ int cg_phase_fused(mag_ctx *ctx)
             ctx->solve_seq = (ctx->solve_seq + 1) & 0xffu;
             if (ctx->solve_seq == 0) ctx->solve_seq = 1;
             ctx->si_tag_base = ctx->solve_seq << 24;
-            ctx->si_epoch = 0;
             ctx->si_spin = 1u << 20;
             if (const char *sp = getenv("MAG_TUNE_STREAM_SPIN")) ctx->si_spin = (uint32_t)atoi(sp); // tests: force the fallback
             // nothing of an earlier use of the inbox may look current: cleared before the all-reduce below lines the ranks up
@@ -1078,6 +1090,9 @@ int cg_phase_fused(mag_ctx *ctx)
         if (int rc = ctx->comm.allreduce_sum(c0, (int64_t)ctx->cwords, s, msg)) return fail(ctx, rc, "%s", msg.c_str());
         magk::fused_setup(c0, ctx->g_all, ctx->g_all, ctx->opt.stop_mode, ctx->opt.tol, (long long)ctx->opt.max_iter,
                           ctx->fstate.as<FusedState>(), s);
+        if (ctx->si) // tags of this solve's exchanges: sequence number << 24 + the launch counter (k_stream_exchange)
+            HIPCHK(hipMemcpyAsync((char *)ctx->fstate.p + offsetof(FusedState, exchange_tag_base), &ctx->si_tag_base, 4,
+                                  hipMemcpyHostToDevice, s));
     } else {
         HIPCHK(hipMemsetAsync(ctx->fpart.p, 0, 8 * 2 * 5 * (size_t)stride, s));
         magk::fused_init(ctx->bP.as<double2>(), ctx->pre ? ctx->minvP.as<float4>() : nullptr, ctx->rqp0.as<magk::Rqp>(),
@@ -1089,7 +1104,9 @@ int cg_phase_fused(mag_ctx *ctx)
     HIPCHK(hipGetLastError());
 
     const int G = ctx->opt.check_every;
-    const bool graph = ctx->opt.use_graph != 0 && !ctx->dist;
+    // one GPU, or several trading through the inboxes (iteration launch + k_stream_exchange, no host work): the block of G
+    // iterations replays from a hipGraph; with an all-reduce per iteration the launches stay eager (RCCL's own enqueue)
+    const bool graph = ctx->opt.use_graph != 0 && (!ctx->dist || ctx->si);
     if (graph)
         if (int rc = ensure_fused_graph(ctx, G)) return rc;
     ctx->exchange_kind = ctx->dist ? (ctx->si ? 3 : 1) : 0;
@@ -1124,6 +1141,7 @@ int cg_phase_fused(mag_ctx *ctx)
         if (flag != 0.0) {
             HIPCHK(hipMemsetAsync(ctx->inbox_own, 0, 64, s)); // the timeout word
             ctx->si_failed = true;
+            ctx->exchange_timed_out = true;
             if (ctx->opt.verbose) printf("info: inbox exchange timed out, falling back to one all-reduce per iteration\n");
             return cg_phase_fused(ctx);
         }
@@ -1272,12 +1290,15 @@ int cg_phase_persist(mag_ctx *ctx)
         // another process, or fewer CUs are usable than reported): use the streaming kernels from now on
         ctx->persist_failed = true;
         ctx->persist_timed_out = true;
+        ctx->persist_backoff = ctx->persist_backoff ? std::min(2 * ctx->persist_backoff, 1024) : 8;
+        ctx->persist_retry_in = ctx->persist_backoff;
         ctx->persist = false;
         if (ctx->opt.verbose) printf("info: on-chip CG not co-resident, falling back to the streaming iteration\n");
         ctx->cg_kernel = 1;
         return cg_phase_fused(ctx);
     }
     ctx->cg_kernel = 2;
+    ctx->persist_backoff = 0; // co-resident again: the next failure starts from the short wait
     ctx->exchange_kind = mg ? 2 : 0;
     if (mg) { // every rank returns the whole solution
         if (int rc = gather_solution(ctx)) return rc;
@@ -1444,6 +1465,9 @@ int cg_phase_fused32(mag_ctx *ctx)
         if (int rc = ctx->comm.allreduce_sum(c0, (int64_t)ctx->cwords, s, msg)) return fail(ctx, rc, "%s", msg.c_str());
         magk::fused_setup(c0, ctx->g_all, ctx->g_all, ctx->opt.stop_mode, ctx->opt.tol, (long long)ctx->opt.max_iter,
                           ctx->fstate.as<FusedState>(), s);
+        if (ctx->si) // tags of this solve's exchanges: sequence number << 24 + the launch counter (k_stream_exchange)
+            HIPCHK(hipMemcpyAsync((char *)ctx->fstate.p + offsetof(FusedState, exchange_tag_base), &ctx->si_tag_base, 4,
+                                  hipMemcpyHostToDevice, s));
     } else {
         HIPCHK(hipMemsetAsync(ctx->fpart.p, 0, 8 * 2 * 4 * (size_t)stride, s));
         magk::fused32_init(ctx->bP.as<double2>(), ctx->rqp32a.as<magk::Rqp32>(), ctx->rqp32b.as<magk::Rqp32>(),
@@ -1754,6 +1778,10 @@ int mag_run(mag_ctx *ctx)
     st = {};
     // every run redoes the whole path: nothing of a previous run is reused except allocations
     ctx->have_order = ctx->have_csr = ctx->have_run = false;
+    // a context whose on-chip kernel once found the GPU shared is not condemned to stream for ever: after a number of
+    // streamed solves (8, doubling per failure) it tries again -- at worst one more spin budget (~0.3 s).  Across ranks
+    // the failures are agreed on collectively, so every rank counts the same and retries in the same solve.
+    if (ctx->persist_failed && --ctx->persist_retry_in <= 0) ctx->persist_failed = false;
     if (ctx->opt.verbose) printf("info: building element stiffness matrices...\n");
 
     HIPCHK(hipEventRecord(ctx->ev[0], s));
@@ -1799,6 +1827,7 @@ int mag_run(mag_ctx *ctx)
     ctx->cg_kernel = csr_op ? 3 : (f32 ? 4 : (ctx->fused ? 1 : 0));
     ctx->exchange_kind = ctx->dist ? 1 : 0; // the phases that trade through the inboxes say so themselves
     ctx->persist_timed_out = false;
+    ctx->exchange_timed_out = false;
     auto cg_dispatch = [&]() {
         return csr_op ? cg_phase_csr(ctx)
                       : (f32 ? cg_phase_fused32(ctx)
@@ -1815,16 +1844,24 @@ int mag_run(mag_ctx *ctx)
         const double best_cost = ctx->best_cost;
         const long long best_iter = ctx->best_iter;
         const int64_t cap = ctx->opt.max_iter;
+        const int kernel1 = ctx->cg_kernel, exchange1 = ctx->exchange_kind;
         ctx->opt.max_iter = best_iter;
         const int rc = cg_dispatch();
         ctx->opt.max_iter = cap;
         if (rc) return rc;
+        // The repeat stands for the first pass only if it WAS the first pass: same kernel, same exchange (a time-out in
+        // either pass changes the path and with it the summation orders), and the cost it reports at best_iter is the
+        // recorded best cost, bit for bit.  Otherwise the caller is told and gets the cost of what is actually returned.
+        const bool same = ctx->cg_kernel == kernel1 && ctx->exchange_kind == exchange1 && st.iterations == best_iter &&
+                          memcmp(&st.final_cost, &best_cost, sizeof(double)) == 0;
+        const double cost2 = st.final_cost;
         st.iterations = first.iterations; // what argmin's observer prints: state.get_iter() (solver.rs:101-104)
         st.converged = 0;
         st.breakdown = 0;
         st.termination = MAG_TERM_MAX_ITERS;
         st.best_iteration = best_iter;
-        st.final_cost = best_cost;
+        st.final_cost = same ? best_cost : cost2;
+        st.best_param_mismatch = same ? 0 : 1;
     }
     HIPCHK(hipEventRecord(ctx->ev[6], s));
     if (ctx->opt.verbose)
@@ -1870,6 +1907,7 @@ int mag_run(mag_ctx *ctx)
     st.n_free = ctx->nf;
     ctx->have_run = true;
     st.persist_timeout = ctx->persist_timed_out ? 1 : 0;
+    st.exchange_timeout = ctx->exchange_timed_out ? 1 : 0;
     if (st.breakdown)
         return fail(ctx, MAG_ERR_NOT_CONVERGED, "Conjugate Gradient error: non-finite residual after %lld iterations",
                     (long long)st.iterations);
@@ -2130,6 +2168,9 @@ int mag_comm_inbox_create(mag_ctx *ctx, uint64_t bytes, void *handle_out)
 {
     if (int rc = enter(ctx)) return rc;
     inbox_release(ctx);
+    // whatever made an exchange through the OLD inboxes give up (another process on the GPU during a trial solve, a peer
+    // that went away) says nothing about new ones
+    ctx->si_failed = false;
     if (bytes == 0) return MAG_OK; // inboxes removed
     if (bytes < 4096 || !handle_out) return fail(ctx, MAG_ERR_BAD_ARGS, "inbox: %llu bytes / null handle", (unsigned long long)bytes);
     static_assert(sizeof(hipIpcMemHandle_t) == MAG_IPC_HANDLE_BYTES, "ipc handle size");

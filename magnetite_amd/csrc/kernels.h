@@ -238,7 +238,7 @@ struct FusedState {
     double best_cost;    // as in CgState
     long long best_iter;
     int exchange_timeout; // multi-GPU, inbox exchange of the streaming kernels: a wait ran out (k_stream_exchange)
-    int pad0;
+    unsigned int exchange_tag_base; // ... and the solve's sequence number << 24: tag of exchange e = base + e (host-written)
     double pad[3];
 };
 struct FusedParams {
@@ -336,8 +336,11 @@ struct PersistParams {
 };
 // multi-GPU, streaming kernels: the per-iteration exchange [dot partials | interface q] through the ranks' device
 // inboxes instead of an all-reduce, in place on `buf` (persist.hip, k_stream_exchange)
+// `fpar` = parity of the iteration launch that has just filled `buf`; the exchange's epoch (hence its inbox parity and
+// its tag) is read from the launch counter that launch left in FusedState: no per-launch host value, so a block of
+// [iteration launch, exchange] pairs replays from a hipGraph
 void stream_exchange_launch(double *buf, int32_t g_all, int32_t n_iface, int32_t rank, int32_t nranks, int32_t own0,
-                            int32_t own1, int32_t par, uint32_t tag, uint32_t spin_limit, const int32_t *iface,
+                            int32_t own1, int32_t fpar, uint32_t spin_limit, const int32_t *iface,
                             const uint8_t *iface_readers, void *const *inboxes, FusedState *st, hipStream_t s);
 int persist_tiles_per_wg(int32_t B); // tiles one workgroup keeps on chip (0: tile size not supported)
 size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh);

@@ -761,8 +761,8 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
 // FusedState::exchange_timeout (and the other ranks' timeout words) and the host falls back to the all-reduce.
 struct StreamExchangeParams {
     double *buf;              // [4 x g_all partial slots | n_iface x double2 q]: the iteration kernel's output, in place
-    int32_t g_all, n_iface, rank, nranks, own0, own1, par;
-    uint32_t tag, spin_limit;
+    int32_t g_all, n_iface, rank, nranks, own0, own1, fpar; // fpar: parity of the iteration launch that filled buf
+    uint32_t spin_limit;
     const int32_t *iface;     // sorted Hilbert ids of the interface nodes
     const uint8_t *iface_readers;
     uint8_t *inbox[8];
@@ -775,6 +775,12 @@ __global__ void __launch_bounds__(256) k_stream_exchange(const StreamExchangePar
     __shared__ double2 s_recs[16];
     const int tid = threadIdx.x, R = P.nranks;
     if (P.st->done) return; // converged (or capped) earlier in this block: every rank takes the same exit
+    // Exchange e follows iteration launch e - 1, which left its successor's number e in jslot[fpar ^ 1] (fused_step): the
+    // epoch, the inbox parity and the tag come from device memory, identical on every rank (all ranks run the same
+    // launches), and nothing in this kernel's arguments changes from one iteration to the next.
+    const uint32_t epoch = (uint32_t)P.st->jslot[P.fpar ^ 1];
+    const int32_t xpar = (int32_t)(epoch & 1u);
+    const uint32_t xtag = P.st->exchange_tag_base + epoch;
     uint8_t *mine = P.inbox[P.rank];
     gu32 *wtmo = (gu32 *)mine;
     double2 *q = (double2 *)(P.buf + 4 * (size_t)P.g_all);
@@ -787,7 +793,7 @@ __global__ void __launch_bounds__(256) k_stream_exchange(const StreamExchangePar
         const double2 v = q[k];
         for (int r = 0; r < R; ++r)
             if (r != P.rank && ((readers >> r) & 1u))
-                put_granules_sys((unsigned long long *)(P.inbox[r] + qoff + 32 * ((size_t)P.par * P.n_iface + k)), P.tag, v);
+                put_granules_sys((unsigned long long *)(P.inbox[r] + qoff + 32 * ((size_t)xpar * P.n_iface + k)), xtag, v);
     }
     // (2) block 0: the rank's sums, fixed order (thread-strided partials, wave trees, the four waves in order)
     if (blockIdx.x == 0) {
@@ -807,20 +813,20 @@ __global__ void __launch_bounds__(256) k_stream_exchange(const StreamExchangePar
             double T[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) T[c] = ((s_red[c][0] + s_red[c][1]) + s_red[c][2]) + s_red[c][3];
-            put_granules_sys((unsigned long long *)(P.inbox[tid >> 1] + 64) + 4 * (2 * ((int64_t)P.par * R + P.rank) + (tid & 1)),
-                             P.tag, (tid & 1) == 0 ? make_double2(T[0], T[1]) : make_double2(T[2], T[3]));
+            put_granules_sys((unsigned long long *)(P.inbox[tid >> 1] + 64) + 4 * (2 * ((int64_t)xpar * R + P.rank) + (tid & 1)),
+                             xtag, (tid & 1) == 0 ? make_double2(T[0], T[1]) : make_double2(T[2], T[3]));
         }
     }
     // (3) wait: the R sums (every block) and the q this rank reads (each block its share of the slots)
-    const unsigned long long *wrec = (const unsigned long long *)(mine + 64) + 8 * (int64_t)P.par * R;
-    const unsigned long long *wq = (const unsigned long long *)(mine + qoff) + 4 * (int64_t)P.par * P.n_iface;
+    const unsigned long long *wrec = (const unsigned long long *)(mine + 64) + 8 * (int64_t)xpar * R;
+    const unsigned long long *wq = (const unsigned long long *)(mine + qoff) + 4 * (int64_t)xpar * P.n_iface;
     bool have_w = tid >= 2 * R || blockIdx.x != 0; // only block 0 turns the sums into the next launch's input
     int32_t k = blockIdx.x * 256 + tid; // one slot at a time per thread
     bool ok_all = false;
     for (unsigned spins = 0; spins < P.spin_limit; ++spins) {
         if (!have_w) {
             double2 v;
-            have_w = get_granules_sys(wrec, 64u * (uint32_t)R, 32u * (uint32_t)tid, P.tag, v);
+            have_w = get_granules_sys(wrec, 64u * (uint32_t)R, 32u * (uint32_t)tid, xtag, v);
             if (have_w) s_recs[tid] = v;
         }
         while (k < P.n_iface) { // advance over the slots that are settled; stop at the first one still on its way
@@ -829,7 +835,7 @@ __global__ void __launch_bounds__(256) k_stream_exchange(const StreamExchangePar
             if (!owned) {
                 if ((P.iface_readers[k] >> P.rank) & 1u) {
                     double2 v;
-                    if (!get_granules_sys(wq, 32u * (uint32_t)P.n_iface, 32u * (uint32_t)k, P.tag, v)) break;
+                    if (!get_granules_sys(wq, 32u * (uint32_t)P.n_iface, 32u * (uint32_t)k, xtag, v)) break;
                     q[k] = v;
                 } else {
                     q[k] = make_double2(0.0, 0.0);
@@ -871,7 +877,7 @@ __global__ void __launch_bounds__(256) k_stream_exchange(const StreamExchangePar
 }
 
 void stream_exchange_launch(double *buf, int32_t g_all, int32_t n_iface, int32_t rank, int32_t nranks, int32_t own0,
-                            int32_t own1, int32_t par, uint32_t tag, uint32_t spin_limit, const int32_t *iface,
+                            int32_t own1, int32_t fpar, uint32_t spin_limit, const int32_t *iface,
                             const uint8_t *iface_readers, void *const *inboxes, FusedState *st, hipStream_t s)
 {
     StreamExchangeParams P = {};
@@ -882,8 +888,7 @@ void stream_exchange_launch(double *buf, int32_t g_all, int32_t n_iface, int32_t
     P.nranks = nranks;
     P.own0 = own0;
     P.own1 = own1;
-    P.par = par;
-    P.tag = tag;
+    P.fpar = fpar;
     P.spin_limit = spin_limit;
     P.iface = iface;
     P.iface_readers = iface_readers;

@@ -174,6 +174,27 @@ def test_eight_ranks_fp32_leg_of_config5(case):
         assert np.array_equal(out["u"], results[0][0]["u"])
 
 
+@pytest.mark.parametrize("inboxes,variant,exchange", [(False, 1, 1), (True, 1, 3), (True, 2, 2)])
+def test_eight_ranks_iteration_cap_returns_best_param(case, inboxes, variant, exchange):
+    """solver.rs:149-176 across ranks: at the iteration cap every rank returns argmin's best_param -- the lowest-cost
+    iterate, recovered by repeating the solve up to that iteration.  The repeat must take the path of the first pass
+    (same kernel, same exchange) and land on the recorded best cost bit for bit: best_param_mismatch == 0."""
+    p, _, _ = case
+    cap = 60
+    ref = oracle.run(p.xy_flat, p.conn_flat, p.u_known, p.u_in, p.f_in, p.youngs_modulus, p.poisson_ratio,
+                     p.part_thickness, path="sparse", max_iter=cap, hist_len=cap)
+    kbest = int(np.argmin(ref["history"])) + 1
+    assert ref["iterations"] == cap and kbest < cap  # the cap falls into a rising stretch of the residual history
+    results = run_ranks(p, inboxes=inboxes, cg_variant=variant, tile_nodes=512, max_iter=cap)
+    for rank, (out,) in enumerate(results):
+        assert out["converged"] == 0 and out["termination"] == _lib.MAG_TERM_MAX_ITERS and out["iterations"] == cap
+        assert out["cg_kernel"] == variant and out["exchange"] == exchange, (rank, out["cg_kernel"], out["exchange"])
+        assert out["best_iteration"] == kbest and out["best_param_mismatch"] == 0, (rank, out["best_iteration"], kbest)
+        assert abs(out["final_cost"] - ref["final_cost"]) <= 1e-9 * ref["final_cost"]
+        assert rel(out["u"], ref["u"]) <= 1e-8
+        assert np.array_equal(out["u"], results[0][0]["u"])
+
+
 def test_config5_eight_ranks_at_baseline_size_against_the_oracle_fixture(built):
     """BASELINE config 5 as written: the 16M-triangle multi-hole mesh split over EIGHT ranks (1M nodes per rank: beyond the
     on-chip kernel, so the streaming kernels trade through the inboxes, k_stream_exchange), relative stop 1e-8; every
