@@ -145,6 +145,7 @@ struct mag_ctx {
     uint32_t si_tag_base = 0, si_spin = 1u << 20; // polls (~2 us each) before an exchange gives up
     int32_t exchange_kind = 0; // mag_stats.exchange of the last run // the on-chip kernel gave up at its grid barrier in this run (mag_stats.persist_timeout)
     int nsums() const { return pre ? 5 : 4; }
+    DevBuf pstamps; // diagnostic build of the on-chip kernel: phase stamps
     DevBuf xy32, hxy32, rqp32a, rqp32b, x32; // fp32 leg (mag_options.precision = 1)
     hipGraphExec_t graph = nullptr;
     struct GraphKey {
@@ -452,7 +453,8 @@ int ensure_order(mag_ctx *ctx)
         int dev = 0, cus = 0;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const int kmax = magk::persist_tiles_per_wg(B);
+        const int pthreads = magk::persist_threads();
+        const int kmax = magk::persist_tiles_per_wg(B, pthreads);
         const int32_t tiles_max = (T + R - 1) / R; // the most tiles any rank runs
         const int k = cus > 0 ? (tiles_max + cus - 1) / cus : 0;
         // Measured against the streaming kernel on the same 512-node tiles the on-chip kernel wins from one tile per
@@ -462,8 +464,8 @@ int ensure_order(mag_ctx *ctx)
         if (const char *e = getenv("MAG_TUNE_PERSIST_MIN_K")) kmin = atoi(e);
         ctx->persist_maxh = ((max_halo + 3) / 4) * 4;
         if (kmax > 0 && k >= 1 && k >= kmin && k <= kmax && (tiles_max + k - 1) / k <= 256 && // the gather holds 256
-            (int64_t)k * max_halo <= 2 * 512 && // a workgroup's halo entries are dealt out two per thread
-            magk::persist_lds_bytes(B, ctx->cap, ctx->persist_maxh) <= 160 * 1024) {
+            (int64_t)k * max_halo <= 2 * pthreads && // a workgroup's halo entries are dealt out two per thread
+            magk::persist_lds_bytes(B, ctx->cap, ctx->persist_maxh, pthreads) <= 160 * 1024) {
             ctx->persist = true;
             ctx->persist_k = k;
             ctx->persist_grid = (ctx->t1 - ctx->t0 + k - 1) / k;
@@ -1262,7 +1264,26 @@ int cg_phase_persist(mag_ctx *ctx)
         HIPCHK(hipMemsetAsync(ctx->comm_pq.p, 0, 8, s));
         if (int rc = ctx->comm.allreduce_sum(ctx->comm_pq.as<double>(), 1, s, msg)) return fail(ctx, rc, "%s", msg.c_str());
     }
-    magk::persist_launch(P, ctx->B, grid + P.comm_wg, s);
+    const bool stamps = magk::persist_stamps_built() && getenv("MAG_TUNE_PERSIST_STAMPS") != nullptr;
+    if (stamps) { // diagnostic build only (scripts/persist_phases.sh): phase times per workgroup
+        HIPCHK(ctx->pstamps.reserve(8 * (size_t)magk::persist_stamp_words() * (size_t)(grid + 1)));
+        HIPCHK(hipMemsetAsync(ctx->pstamps.p, 0, 8 * (size_t)magk::persist_stamp_words() * (size_t)(grid + 1), s));
+        P.stamps = ctx->pstamps.as<unsigned long long>();
+    }
+    magk::persist_launch(P, ctx->B, grid + P.comm_wg, magk::persist_threads(), s);
+    if (stamps) {
+        std::vector<unsigned long long> h((size_t)magk::persist_stamp_words() * (size_t)grid);
+        HIPCHK(hipMemcpyAsync(h.data(), ctx->pstamps.p, 8 * h.size(), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (FILE *f = fopen(getenv("MAG_TUNE_PERSIST_STAMPS"), "w")) {
+            for (int g = 0; g < grid; ++g) {
+                for (int k = 0; k < magk::persist_stamp_words(); ++k)
+                    fprintf(f, "%s%llu", k ? "," : "", h[(size_t)g * magk::persist_stamp_words() + k]);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+    }
     HIPCHK(hipGetLastError());
     uint32_t h_sync[16] = {};
     HIPCHK(hipMemcpyAsync(&ctx->h_fstate[2], ctx->fstate.p, sizeof(FusedState), hipMemcpyDeviceToHost, s));

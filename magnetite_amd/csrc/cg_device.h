@@ -92,7 +92,15 @@ __device__ inline void fan_force(const V2 db, const V2 ub, const V2 dc, const V2
 // unconditional gathers, the loop bound is a scalar (tile-uniform) branch, and only the ADDITION of a triangle's force
 // is selected by the break bit (a repeated entry spans no area: its force is NaN/inf and is selected out, never
 // multiplied in).  With two waves per SIMD the exec-mask bookkeeping of the branchy walk is pure issue-slot cost.
-template <int NW>
+// NU: entries walked as ONE straight-line block when the tile's rows have at least that many (a closed fan of valence 6
+// is 7 entries: the rule on the benchmark meshes).  A scalar test per entry makes every entry its own basic block, and the
+// instruction scheduler works per block: the chain  2A -> v_rcp_f64 -> two Newton steps -> weight -> force  of one
+// entry (~12 dependent fp64 operations) then cannot overlap the next entry's, and in-kernel stamps showed a wave stalled
+// on its own dependencies half of the time even when it wins every arbitration (profiles/r03_persist_phases.json).  In
+// one block the gathers of all NU entries issue up front and the NU - 1 chains interleave.
+// A second block, entries NU .. NU2 - 1, is walked the same way when the rows have at least NU2 entries (ROCm 7.2's
+// iterative-ilp scheduler, the fastest for this kernel, crashes on blocks of more than four triangles).
+template <int NW, int NU = 1, int NU2 = NU>
 __device__ inline void ring_walk_uniform(const uint32_t (&w)[NW], const uint32_t *more, int32_t stride, int32_t nent,
                                          const double2 *s_xy, const double2 *s_p, const double2 ca, const double2 pa,
                                          double c0, double nu, double h, double &fx, double &fy)
@@ -112,10 +120,27 @@ __device__ inline void ring_walk_uniform(const uint32_t (&w)[NW], const uint32_t
         pd = d;
         pu = u;
     };
+    auto entry = [&](int k) { return (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu); };
     step(w[0] & 0xffffu, true);
+    if (NU > 1 && nent >= NU) { // nent: a scalar
 #pragma unroll
-    for (int k = 1; k < 2 * NW; ++k)
-        if (k < nent) step((k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu), false); // nent: a scalar
+        for (int k = 1; k < NU; ++k) step(entry(k), false);
+    } else {
+#pragma unroll
+        for (int k = 1; k < NU; ++k)
+            if (k < nent) step(entry(k), false);
+    }
+    if (NU2 > NU && nent >= NU2) {
+#pragma unroll
+        for (int k = NU; k < NU2; ++k) step(entry(k), false);
+    } else {
+#pragma unroll
+        for (int k = NU; k < NU2; ++k)
+            if (k < nent) step(entry(k), false);
+    }
+#pragma unroll
+    for (int k = NU2; k < 2 * NW; ++k)
+        if (k < nent) step(entry(k), false);
     for (int32_t k = 2 * NW; k < nent; ++k) {
         const uint32_t ww = more[(int64_t)(k >> 1) * stride];
         step((k & 1) ? (ww >> 16) : (ww & 0xffffu), false);

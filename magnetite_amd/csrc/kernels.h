@@ -333,6 +333,7 @@ struct PersistParams {
     int32_t comm_wg; // 1: the grid ends with an exchange workgroup (persist_comm_loop); device inboxes only
     const uint8_t *iface_readers; // n_iface: bit r set when rank r reads the interface node of that slot
     unsigned long long *grec;    // device: 2 * 8 granules, the grid-wide sums republished by workgroup 0
+    unsigned long long *stamps;  // diagnostic build (-DMAG_PERSIST_STAMPS) only: per workgroup, phase times in 10 ns ticks
 };
 // multi-GPU, streaming kernels: the per-iteration exchange [dot partials | interface q] through the ranks' device
 // inboxes instead of an all-reduce, in place on `buf` (persist.hip, k_stream_exchange)
@@ -342,9 +343,12 @@ struct PersistParams {
 void stream_exchange_launch(double *buf, int32_t g_all, int32_t n_iface, int32_t rank, int32_t nranks, int32_t own0,
                             int32_t own1, int32_t fpar, uint32_t spin_limit, const int32_t *iface,
                             const uint8_t *iface_readers, void *const *inboxes, FusedState *st, hipStream_t s);
-int persist_tiles_per_wg(int32_t B); // tiles one workgroup keeps on chip (0: tile size not supported)
-size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh);
-void persist_launch(const PersistParams &P, int32_t B, int32_t grid, hipStream_t s); // MG kernel when nranks > 1
+int persist_threads(); // workgroup shape of the on-chip kernel: 512 (x 4 nodes per lane) or 768 (x 3); MAG_TUNE_PERSIST_THREADS
+int persist_tiles_per_wg(int32_t B, int threads); // tiles one workgroup keeps on chip (0: tile size not supported)
+size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh, int threads);
+void persist_launch(const PersistParams &P, int32_t B, int32_t grid, int threads, hipStream_t s); // MG kernel when nranks > 1
+int persist_stamp_words();   // words per workgroup in PersistParams::stamps
+bool persist_stamps_built(); // the library was compiled with -DMAG_PERSIST_STAMPS
 void mark_published(const int32_t *halo_g, int64_t halo_total, uint8_t *maskP, hipStream_t s);
 
 // ---- fp32 leg of BASELINE config 5 (fp64 vs fp32 CG tolerance sweep): the fused iteration with the CG state, the

@@ -22,7 +22,18 @@ namespace magk {
 // Same recurrences and state machine as k_cg_fused (alpha, beta from the four exact sums of the previous iterate).
 // MG instantiation: several GPUs, each running its tile range, exchanging through per-rank inboxes (further down).
 typedef __attribute__((address_space(1))) unsigned int gu32;
-constexpr int kPersistThreads = 512; // 8 waves per CU = 2 per SIMD: 256 VGPRs per lane, no spills with 4 nodes per thread
+// Two shapes of the workgroup, both keeping four 512-node tiles (2048 nodes) per CU:
+//   512 threads x 4 nodes per lane: 8 waves = 2 per SIMD, up to 256 VGPRs per lane (round 1-2);
+//   768 threads x 3 nodes per lane: 12 waves = 3 per SIMD, 168 VGPRs per lane -- a third wave per SIMD to cover LDS
+//       gather latency (round 2's counters: waves parked 0.52 of the time, vector pipe busy 0.49); local node n of the
+//       workgroup sits in lane n % 768, slot n / 768, so waves 0-7 carry three nodes per lane and waves 8-11 two, and
+//       every SIMD (waves w, w + 4, w + 8) still gets eight node-slots.  Built and measured in round 3 (-DMAG_PERSIST_768,
+//       MAG_TUNE_PERSIST_THREADS=768; profiles/r03_persist_phases.json): 11.55 against 11.07 us per iteration at 1M
+//       triangles, 6.41 against 5.46 at 100k -- the ring walks are bound by fp64 issue, not by latency (the stamps show
+//       the walks of a workgroup taking 7.7 against 7.3 us), and a 12-wave workgroup pays more at every barrier.  Not
+//       instantiated in the product.
+// Local node n = slot * THREADS + lane belongs to local tile n / B: uniform over a wave (64 | B, 64 | THREADS).
+constexpr int kPersistThreadsDefault = 512;
 
 // Inter-workgroup exchange by self-validating granules (CDNA4 guide, Guideline 16 R2: "the data IS the flag"): every
 // handed-off 32-bit half travels in its own naturally aligned 8-byte word {value, tag = epoch}; two of them are written
@@ -89,7 +100,8 @@ __device__ inline double wave_sum_dpp(double v)
 // Returns false when the spin budget runs out (some workgroup is not running): the timeout word is set for the host.
 template <int NH>
 __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigned epoch, const int32_t (&hg)[NH],
-                                        double2 (&hq)[NH], double *s_S, double2 *s_rec, double *s_chunk)
+                                        double2 (&hq)[NH], double *s_S, double2 *s_rec, double *s_chunk,
+                                        unsigned long long *stamp = nullptr)
 {
     const int tid = threadIdx.x;
     const int grid = gridDim.x;
@@ -111,6 +123,9 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
     // s_sleep(32) 10.74, one s_sleep(40) 10.79; the same 40 units as a run-time loop of ten s_sleep(4) 10.87.
     __builtin_amdgcn_s_sleep(18);
     __builtin_amdgcn_s_sleep(14);
+#ifdef MAG_PERSIST_STAMPS
+    if (stamp) stamp[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     for (unsigned spins = 0; spins < P.spin_limit; ++spins) {
         bool ok = true;
         if (!have_rec) {
@@ -127,6 +142,12 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
             }
         if (__syncthreads_and(ok ? 1 : 0)) {
             done = true;
+#ifdef MAG_PERSIST_STAMPS
+            if (stamp) {
+                stamp[1] = __builtin_amdgcn_s_memrealtime();
+                stamp[2] = spins + 1;
+            }
+#endif
             break;
         }
         if ((spins & 255u) == 255u) { // somebody else gave up: do not wait for a grid that will never be complete
@@ -481,8 +502,10 @@ __device__ inline void persist_comm_loop(const PersistParams &P, double *s_S, do
 
 // Workgroup totals of four partial sums for the two publishing threads (0 and 1): DPP wave trees, then the eight
 // waves in order.
+template <int THREADS>
 __device__ inline void persist_block_sum(double (&acc)[4], double *s_red)
 {
+    constexpr int kPersistThreads = THREADS;
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] = wave_sum_dpp(acc[c]);
     if ((threadIdx.x & 63) == 0) {
@@ -502,25 +525,52 @@ __device__ inline void persist_block_sum(double (&acc)[4], double *s_red)
 }
 
 constexpr int kPersistRegs = 5; // ring words in registers per node: 10 entries, a closed fan of valence <= 9
-constexpr int kPersistNpt = 4;  // nodes (tiles) per thread
-constexpr int kPersistNh = 2;   // halo entries per thread: a workgroup's tiles may carry 1024 halo nodes in all
+#ifndef MAG_PERSIST_BLOCK
+#define MAG_PERSIST_BLOCK 5 // measured on one box (us per iteration, 1M triangles): no block 11.06-11.10, 5: 11.02, 4+3: 11.19-11.21,
+#endif                      // 5+2: 11.14; one block of 7 only compiles without iterative-ilp: 11.41-11.71 (profiles/r03_persist_ab.txt)
+#ifndef MAG_PERSIST_BLOCK2
+#define MAG_PERSIST_BLOCK2 MAG_PERSIST_BLOCK
+#endif
+// ring entries walked as straight-line blocks: 1 .. BLOCK - 1 and BLOCK .. BLOCK2 - 1 (cg_device.h, ring_walk_uniform)
+constexpr int kPersistBlock = MAG_PERSIST_BLOCK, kPersistBlock2 = MAG_PERSIST_BLOCK2;
+constexpr int kPersistNh = 2;   // halo entries per thread: a workgroup's tiles may carry 2 * THREADS halo nodes in all
+constexpr int persist_npt(int threads) { return threads == 768 ? 3 : 4; } // nodes per lane
 
-template <int B, bool MG>
-__global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistParams P)
+// Phase stamps (diagnostic build only: -DMAG_PERSIST_STAMPS, scripts/persist_phases.sh): lane 0 of every workgroup reads
+// the 100 MHz constant clock at the phase boundaries of iterations [kStampFrom, kStampTo) and adds the differences up
+// in registers; at the end it writes them to PersistParams::stamps (memory nothing else in the kernel reads; no output
+// value is computed from them).  In the product build no stamp executes and the buffer is never touched.
+#ifdef MAG_PERSIST_STAMPS
+#define MAG_STAMP(k)                                                                                                   \
+    if (stamping) {                                                                                                    \
+        const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();                                              \
+        stamp_sum[k] += now_ - stamp_last;                                                                             \
+        stamp_last = now_;                                                                                             \
+    }
+#else
+#define MAG_STAMP(k)
+#endif
+constexpr int kStampFrom = 200, kStampTo = 1200, kStampPhases = 8;
+
+template <int B, bool MG, int THREADS>
+__global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
 {
-    constexpr int TG = kPersistThreads / B; // thread groups; each owns kPersistNpt of the workgroup's tiles
-    constexpr int NPT = kPersistNpt;
+    constexpr int kPersistThreads = THREADS;
+    constexpr int NPT = persist_npt(THREADS);
     extern __shared__ __attribute__((aligned(16))) double2 smem[];
-    const int tid = threadIdx.x, gi = tid / B, lt = tid % B;
+    const int tid = threadIdx.x;
     const int cap = P.cap, maxh = P.maxh;
     // LDS per local tile l: coordinates[cap], p image[cap] (owned part = the CG vector p itself), halo r[maxh],
     // halo p[maxh], x[B].  Registers per node: r, q, the ring words.
     const int tile_words = 2 * cap + 2 * maxh + B;
-    double2 *s_rec = smem + (size_t)NPT * TG * tile_words; // 2 * grid pieces of the partial records
+    double2 *s_rec = smem + (size_t)(NPT * THREADS / B) * tile_words; // 2 * grid pieces of the partial records
     double *s_red = (double *)(s_rec + 2 * 256);
     double *s_S = s_red + 4 * (kPersistThreads / 64);
     double *s_chunk = s_S + 4;
-    auto t_xy = [&](int s) { return smem + (size_t)(gi + TG * s) * tile_words; };
+    // slot s of this lane: local node s * THREADS + tid, in local tile (s * THREADS + tid) / B (a scalar: wave-uniform)
+    auto t_loc = [&](int s) { return __builtin_amdgcn_readfirstlane((s * THREADS + tid) / B); };
+    auto t_lt = [&](int s) { return (s * THREADS + tid) % B; };
+    auto t_xy = [&](int s) { return smem + (size_t)t_loc(s) * tile_words; };
 
     const int cgrid = (int)gridDim.x - (MG ? P.comm_wg : 0); // compute workgroups (an exchange workgroup may follow them)
     if (MG && P.comm_wg && (int)blockIdx.x == cgrid) {
@@ -539,7 +589,7 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < NPT; ++s) {
-        const int l = gi + TG * s;
+        const int l = t_loc(s), lt = t_lt(s);
         const int32_t t = (MG ? P.t0 : 0) + blockIdx.x * P.tiles_per_wg + l;
         double2 *xy = t_xy(s), *pim = xy + cap, *hr = pim + cap, *hp = hr + maxh, *xs = hp + maxh;
         node[s] = 0;
@@ -609,7 +659,7 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
         }
     }
     if (blockIdx.x == 0 && tid == 0) acc[1] = 1.0; // "p.q" > 0: alpha finite, multiplies q = 0
-    persist_block_sum(acc, s_red);
+    persist_block_sum<THREADS>(acc, s_red);
     int par = 0;
     unsigned epoch = tag0; // the tags of successive exchanges
     if (tid < 2) // the block sums are in every thread: two threads publish the record's two pieces
@@ -632,7 +682,18 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
         s_chunk[0] = __builtin_inf();
         ((long long *)s_chunk)[1] = 0;
     }
+#ifdef MAG_PERSIST_STAMPS
+    unsigned long long stamp_sum[kStampPhases] = {}, stamp_last = 0;
+    unsigned long long stamp_iters = 0;
+#endif
     for (;;) {
+#ifdef MAG_PERSIST_STAMPS
+        const bool stamping = tid == 0 && j >= kStampFrom && j < kStampTo;
+        if (stamping) {
+            stamp_last = __builtin_amdgcn_s_memrealtime();
+            ++stamp_iters;
+        }
+#endif
         const double S0 = s_S[0], S1 = s_S[1], S2 = s_S[2], S3 = s_S[3];
         if (j == 0) {
             bb = S0;
@@ -662,6 +723,7 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
 #pragma unroll
         for (int s = 0; s < NPT; ++s) {
             if (!(flags[s] & 8)) continue;
+            const int lt = t_lt(s);
             double2 *xy = t_xy(s), *pim = xy + cap, *hr = pim + cap, *hp = hr + maxh, *xs = hp + maxh;
             const double2 po = pim[lt];
             double2 xo = xs[lt], pn;
@@ -687,7 +749,9 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
                 hbase[2 * cap + maxh] = hpv;
                 hbase[cap + B] = hpv;
             }
+        MAG_STAMP(0) // scalars + vector updates issued
         __syncthreads();
+        MAG_STAMP(1) // ... landed in LDS for everybody (workgroup barrier)
 
         // ---- q = M K M p on the owned nodes, dot partials, publication
 #pragma unroll
@@ -695,13 +759,14 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
 #pragma unroll
         for (int s = 0; s < NPT; ++s) {
             if (!(flags[s] & 8)) continue;
+            const int lt = t_lt(s);
             const double2 *xy = t_xy(s), *pim = xy + cap;
             const double2 ca = xy[lt], pa = pim[lt];
             double fx = 0.0, fy = 0.0;
             {
                 const int32_t nent = __builtin_amdgcn_readfirstlane(ent[s]); // one tile per wave: a scalar
                 if (nent > 0)
-                    ring_walk_uniform<kPersistRegs>(w[s], P.ell16 + ell_off[s], B, nent, xy, pim, ca, pa, c0, nu, h, fx,
+                    ring_walk_uniform<kPersistRegs, kPersistBlock, kPersistBlock2>(w[s], P.ell16 + ell_off[s], B, nent, xy, pim, ca, pa, c0, nu, h, fx,
                                                     fy);
             }
             if ((flags[s] & 1) || !(flags[s] & 16)) fx = 0.0;
@@ -715,21 +780,43 @@ __global__ void __launch_bounds__(kPersistThreads) k_cg_persist(const PersistPar
             acc[2] += r[s].x * fx + r[s].y * fy;
             acc[3] += fx * fx + fy * fy;
         }
-        persist_block_sum(acc, s_red);
+        MAG_STAMP(2) // ring walks of this wave's nodes, q published
+        persist_block_sum<THREADS>(acc, s_red);
         par ^= 1;
         ++epoch;
         ++j;
         if (tid < 2)
             put_granules(P.recg + 4 * (2 * ((int64_t)par * cgrid + blockIdx.x) + tid), epoch,
                          tid == 0 ? make_double2(acc[0], acc[1]) : make_double2(acc[2], acc[3]));
+        MAG_STAMP(3) // workgroup sums (wave trees, barrier, eight waves in order) + record published
+#ifdef MAG_PERSIST_STAMPS
+        unsigned long long xs_[3] = {0, 0, 0};
+        if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec)
+               : !persist_exchange<NH>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk, stamping ? xs_ : nullptr))
+            return;
+        if (stamping) { // inside the exchange: wait before the first sweep / sweeps until complete / record reduction
+            stamp_sum[4] += xs_[0] - stamp_last;
+            stamp_sum[5] += xs_[1] - xs_[0];
+            stamp_sum[6] += __builtin_amdgcn_s_memrealtime() - xs_[1];
+            stamp_sum[7] += xs_[2]; // sweeps taken
+        }
+#else
         if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec)
                : !persist_exchange<NH>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk))
             return;
+#endif
     }
+#ifdef MAG_PERSIST_STAMPS
+    if (tid == 0 && P.stamps) {
+        unsigned long long *o = P.stamps + (size_t)blockIdx.x * (kStampPhases + 1);
+        for (int k = 0; k < kStampPhases; ++k) o[k] = stamp_sum[k];
+        o[kStampPhases] = stamp_iters;
+    }
+#endif
     // x of iterate j-1 is in LDS; the verdict is the same in every workgroup
 #pragma unroll
     for (int s = 0; s < NPT; ++s)
-        if ((flags[s] & 24) == 24) P.x[node[s]] = (t_xy(s) + 2 * cap + 2 * maxh)[lt];
+        if ((flags[s] & 24) == 24) P.x[node[s]] = (t_xy(s) + 2 * cap + 2 * maxh)[t_lt(s)];
     if (blockIdx.x == 0 && tid == 0) {
         FusedState *st = P.st;
         st->bb = bb;
@@ -899,27 +986,61 @@ void stream_exchange_launch(double *buf, int32_t g_all, int32_t n_iface, int32_t
     k_stream_exchange<<<blocks, 256, 0, s>>>(P);
 }
 
-int persist_tiles_per_wg(int32_t B) { return B == 256 || B == 512 ? kPersistNpt * (kPersistThreads / B) : 0; }
-
-size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh)
+int persist_threads()
 {
-    const size_t tiles = (size_t)kPersistNpt * (kPersistThreads / B);
-    return tiles * (2 * (size_t)cap + 2 * (size_t)maxh + (size_t)B) * 16 + 2 * 256 * 16 +
-           (4 * (kPersistThreads / 64) + 4 + 4 * 32) * 8 + 16;
+    const char *e = getenv("MAG_TUNE_PERSIST_THREADS");
+    const int t = e ? atoi(e) : kPersistThreadsDefault;
+#ifdef MAG_PERSIST_768 // the 768 x 3 shape is only instantiated on request: measured 4 % slower (see the top of this file)
+    return t == 768 ? 768 : 512;
+#else
+    (void)t;
+    return 512;
+#endif
 }
 
-void persist_launch(const PersistParams &P, int32_t B, int32_t grid, hipStream_t s)
+int persist_tiles_per_wg(int32_t B, int threads)
 {
-    const size_t lds = persist_lds_bytes(B, P.cap, P.maxh);
+    return B == 256 || B == 512 ? persist_npt(threads) * threads / B : 0; // whole tiles: 768 x 3 / 512 = 4
+}
+
+size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh, int threads)
+{
+    const size_t tiles = (size_t)persist_tiles_per_wg(B, threads);
+    return tiles * (2 * (size_t)cap + 2 * (size_t)maxh + (size_t)B) * 16 + 2 * 256 * 16 +
+           (4 * ((size_t)threads / 64) + 4 + 4 * 32) * 8 + 16;
+}
+
+template <int THREADS>
+static void persist_launch_t(const PersistParams &P, int32_t B, int32_t grid, size_t lds, hipStream_t s)
+{
     if (P.nranks > 1) {
         if (B == 256)
-            k_cg_persist<256, true><<<grid, kPersistThreads, lds, s>>>(P);
+            k_cg_persist<256, true, THREADS><<<grid, THREADS, lds, s>>>(P);
         else
-            k_cg_persist<512, true><<<grid, kPersistThreads, lds, s>>>(P);
+            k_cg_persist<512, true, THREADS><<<grid, THREADS, lds, s>>>(P);
     } else if (B == 256)
-        k_cg_persist<256, false><<<grid, kPersistThreads, lds, s>>>(P);
+        k_cg_persist<256, false, THREADS><<<grid, THREADS, lds, s>>>(P);
     else
-        k_cg_persist<512, false><<<grid, kPersistThreads, lds, s>>>(P);
+        k_cg_persist<512, false, THREADS><<<grid, THREADS, lds, s>>>(P);
+}
+
+void persist_launch(const PersistParams &P, int32_t B, int32_t grid, int threads, hipStream_t s)
+{
+    const size_t lds = persist_lds_bytes(B, P.cap, P.maxh, threads);
+#ifdef MAG_PERSIST_768
+    if (threads == 768) return persist_launch_t<768>(P, B, grid, lds, s);
+#endif
+    persist_launch_t<512>(P, B, grid, lds, s);
+}
+
+int persist_stamp_words() { return kStampPhases + 1; }
+bool persist_stamps_built()
+{
+#ifdef MAG_PERSIST_STAMPS
+    return true;
+#else
+    return false;
+#endif
 }
 
 // bit 2 of the node mask: some tile reads this node through its halo list, so its owner must publish q
