@@ -4,6 +4,8 @@
 // the k=0 product (gemm -> gemv -> axcpy), so K_e, the assembled K, the RHS
 // and the stress scalar reproduce the reference's rounding, not just its
 // formulas.  None of these kernels is in the CG loop.
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -241,6 +243,7 @@ constexpr int kAsmNodes = 128; // row nodes (threads) per tile
 constexpr int kAsmSlots = 8;   // 2x2 blocks a row may hold in its LDS accumulators (valence 6 interior node: 7)
 constexpr int kAsmBatch = 4;   // incidence entries whose gathers a thread issues together (the kernel is latency-bound)
 
+template <int STRIDE = kAsmNodes>
 __device__ inline void asm_entry(const int32_t (&nn)[3], int a, const double2 v0, const double2 v1, const double2 v2,
                                  const double *D, double thick, const int32_t (&col)[kAsmSlots], double2 *s_top,
                                  double2 *s_bot, int lane)
@@ -275,13 +278,13 @@ __device__ inline void asm_entry(const int32_t (&nn)[3], int a, const double2 v0
         int kpos = 0; // position of n_b among the row's ascending columns (it is one of them)
 #pragma unroll
         for (int k = 0; k < kAsmSlots; ++k) kpos += col[k] < nn[b] ? 1 : 0;
-        double2 top = s_top[kpos * kAsmNodes + lane], bot = s_bot[kpos * kAsmNodes + lane];
+        double2 top = s_top[kpos * STRIDE + lane], bot = s_bot[kpos * STRIDE + lane];
         top.x += c00;
         top.y += c01;
         bot.x += c10;
         bot.y += c11;
-        s_top[kpos * kAsmNodes + lane] = top;
-        s_bot[kpos * kAsmNodes + lane] = bot;
+        s_top[kpos * STRIDE + lane] = top;
+        s_bot[kpos * STRIDE + lane] = bot;
     }
 }
 
@@ -401,6 +404,343 @@ void assemble_tiles(const int32_t *bcol, const int32_t *bptr, const int32_t *inc
     const int64_t tiles = (N + kAsmNodes - 1) / kAsmNodes;
     k_assemble_tiles<<<(unsigned)tiles, kAsmNodes, 0, s>>>(bcol, bptr, inc_off, inc, perm, conn, (const double2 *)xy, N,
                                                            nu, youngs, thick, kval);
+}
+
+// ---- the same assembly fed from the CG TILES (round 3; the shape BASELINE.json's north star names: "LDS staging of node
+// coordinates and coalesced HBM reads of the element->node index arrays") -------------------------------------------
+// k_assemble_tiles walks  incidence entry -> connectivity triple -> three coordinates  in caller numbering (three
+// dependent gathers per (node, element), 4.7 x the algorithmic read traffic), every thread loads its row's columns and
+// stores its row's blocks by itself (each of those wave instructions touches 64 different cache lines; PMC: L1 stalled on
+// pending requests 57 % of the launch, 128 MB written for 112 MB of K), and its accumulators -- 256 bytes of LDS per row
+// node -- cap the CU at ten waves, too few to cover any of that.  Measured in round 3: feeding the same
+// thread-per-row kernel from the CG tiles and storing row-wise brought 76 -> 70 us; what remained was the latency of a
+// workgroup's serial phases with two waves per SIMD.  This kernel drops the accumulators:
+//
+//   ONE LANE PER (row node a, incident triangle (a, b, c)), eight lanes per node -- a wave holds eight nodes.
+//
+// The ordering phase has already built, per tile of B consecutive Hilbert nodes, what the gathers look up: the tile's owned
+// + halo coordinates as two contiguous runs (xyP, halo_xy) and, per node, one word per incident element in ascending
+// element order -- the two OTHER corners as tile-local ids (symbolic.hip, k_fill_ell16; kept for this kernel with the
+// node's corner label in the spare bits: lb | label << 12 | lc << 16, orientation a -> b -> c of the reference's vertex
+// order).  A lane evaluates its triangle once (asm_fan_blocks: the rotated frame; only the ORDER in which solver.rs:187-193
+// sums the three products of the signed area depends on the label) and holds the three blocks of row a it contributes
+// to: the diagonal's share, the block of column b, the block of column c.  Then, per row:
+//   * an off-diagonal block (a, n) receives at most two contributions in a manifold mesh -- from the triangle that has n
+//     as its b and the one that has it as its c, the two sides of the edge a-n.  The reference adds them in ascending
+//     element order, (0.0 + c1) + c2; IEEE addition is commutative (and (0.0 + x) + y = (0.0 + y) + x also when signed
+//     zeros are involved), so the b-side lane fetches its partner's c-side block from LDS, forms (0.0 + own) + partner's
+//     and stores the finished block; a c with no b-side partner (the open end of a boundary fan) is stored by its own lane;
+//   * the diagonal block receives one contribution per triangle and there the order does matter: the lanes of a node hold
+//     their triangles in ascending element order (slot order of the table), the node's first lane adds the shares up from
+//     LDS in that order, starting from 0.0;
+//   * the row's columns are loaded by the node's lanes (lane k its k-th column: one 32-byte run), and every store goes into
+//     the row's one contiguous run of 32 * cnt bytes: reads and writes are row-wise by construction.
+// No accumulators: the image (20 bytes per staged node) and 64 bytes per lane of exchange space make ~33 KB of LDS per
+// 256-thread workgroup -- four workgroups (16 waves) per CU.  The seven quotients of `B /= 2A` share their denominator:
+// with r = RN(1 / 2A) (one true division) each quotient is x r corrected twice with exact FMA residuals (Markstein's
+// sequence, the one IA-64 and POWER divide with): RN(x / 2A), the reference's bits, in 5 instructions instead of a
+// ~13-instruction division each.  Valid while nothing under- or overflows and 2A's significand is not all ones:
+// guaranteed per tile by a range check of the staged coordinates (0 or 1e-150 < |c| < 1e100, so a non-zero difference is
+// >= 2e-166) and per element by 1e-100 < |2A| < 1e100; otherwise the true divisions run.
+// Rows the scheme does not cover -- more than 8 triangles or 8 blocks, an edge with three or more triangles, an element
+// that lists a node twice -- are finished by the whole workgroup with the k_assemble_rows arithmetic (label order, true
+// divisions), as in k_assemble_tiles.  Tiles whose image does not fit fall back to k_assemble_tiles altogether.
+__device__ inline double div_shared(double x, double d, double r)
+{
+    double q = x * r;
+    double e = __builtin_fma(-d, q, x);
+    q = __builtin_fma(e, r, q);
+    e = __builtin_fma(-d, q, x);
+    return __builtin_fma(e, r, q);
+}
+
+__device__ inline bool coord_in_range(double c)
+{
+    const double a = fabs(c);
+    return c == 0.0 || (a > 1e-150 && a < 1e100);
+}
+
+// The three 2x2 blocks of row a from triangle (a, b, c), the three nodes distinct, in the rotated frame: dg = K_e[a][a],
+// kb = K_e[a][b], kc = K_e[a][c], each entry with the reference's operations ((B^T D) B, ascending-k sums from the first
+// product, * area * thickness).  What depends on the label of a is only the order of the area's three products:
+// label order is (a, b, c) for label 0, (c, a, b) for label 1, (b, c, a) for label 2.
+__device__ inline void asm_fan_blocks(int a, const double2 va, const double2 vb, const double2 vc, const double *D,
+                                      double thick, bool sane, double (&dg)[4], double (&kb)[4], double (&kc)[4])
+{
+    const double nba = vb.y - vc.y, nbb = vc.y - va.y, nbc = va.y - vb.y; // numerators of beta_a, beta_b, beta_c
+    const double nga = vc.x - vb.x, ngb = va.x - vc.x, ngc = vb.x - va.x; // ... of gamma_a, gamma_b, gamma_c
+    const double Ta = va.x * nba, Tb = vb.x * nbb, Tc = vc.x * nbc;
+    const double t1 = a == 0 ? Ta : (a == 1 ? Tc : Tb);
+    const double t2 = a == 0 ? Tb : (a == 1 ? Ta : Tc);
+    const double t3 = a == 0 ? Tc : (a == 1 ? Tb : Ta);
+    const double area = 0.5 * (t1 + t2 + t3);
+    const double d = 2.0 * area;
+    double ba, bb, bc, ga, gb, gc, z;
+    const unsigned long long dbits = (unsigned long long)__double_as_longlong(d);
+    const bool quick = sane && fabs(d) > 1e-100 && fabs(d) < 1e100 &&
+                       (dbits & 0x000fffffffffffffull) != 0x000fffffffffffffull;
+    if (quick) {
+        const double r = 1.0 / d; // correctly rounded: the one true division
+        ba = div_shared(nba, d, r);
+        bb = div_shared(nbb, d, r);
+        bc = div_shared(nbc, d, r);
+        ga = div_shared(nga, d, r);
+        gb = div_shared(ngb, d, r);
+        gc = div_shared(ngc, d, r);
+        z = __builtin_copysign(0.0, d); // 0.0 / d for a finite non-zero d
+    } else {
+        ba = nba / d;
+        bb = nbb / d;
+        bc = nbc / d;
+        ga = nga / d;
+        gb = ngb / d;
+        gc = ngc / d;
+        z = 0.0 / d; // the structural zeros of B after the division
+    }
+    // rows 2a, 2a+1 of B^T D, as ke_block forms them: columns (ba, z, ga) and (z, ga, ba) of B
+    double Mx[3], My[3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        double sx = ba * D[m];
+        sx = sx + z * D[3 + m];
+        sx = sx + ga * D[6 + m];
+        Mx[m] = sx;
+        double sy = z * D[m];
+        sy = sy + ga * D[3 + m];
+        sy = sy + ba * D[6 + m];
+        My[m] = sy;
+    }
+    auto block = [&](double bn, double gn, double (&c)[4]) {
+        double t;
+        t = Mx[0] * bn; t = t + Mx[1] * z;  t = t + Mx[2] * gn; c[0] = t * area * thick;
+        t = Mx[0] * z;  t = t + Mx[1] * gn; t = t + Mx[2] * bn; c[1] = t * area * thick;
+        t = My[0] * bn; t = t + My[1] * z;  t = t + My[2] * gn; c[2] = t * area * thick;
+        t = My[0] * z;  t = t + My[1] * gn; t = t + My[2] * bn; c[3] = t * area * thick;
+    };
+    block(ba, ga, dg);
+    block(bb, gb, kb);
+    block(bc, gc, kc);
+}
+
+__device__ inline void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+constexpr int kFanThreads = 256; // 32 nodes x 8 lanes per pass
+constexpr int kFanLanes = 8;     // lanes (triangles, columns) per node
+
+template <int B>
+__global__ void __launch_bounds__(kFanThreads) k_assemble_fan(const int32_t *bcol, const int32_t *bptr, const uint32_t *perm,
+                                                              const double2 *xyP, const double2 *halo_xy,
+                                                              const int32_t *halo_g, const int32_t *tile_hoff,
+                                                              const int32_t *tile_deg, const int64_t *tile_off,
+                                                              const uint32_t *ell_asm, const int32_t *inc_off,
+                                                              const uint32_t *inc, const int32_t *conn, const double2 *xy,
+                                                              int64_t N, int32_t cap, int32_t img_pieces, int32_t segs,
+                                                              double nu, double youngs, double thick, double *kval)
+{
+    extern __shared__ __attribute__((aligned(16))) double2 s_asm[];
+    double2 *s_xy = s_asm;                                   // [cap] coordinates of the tile's owned + halo nodes
+    int32_t *s_cid = (int32_t *)(s_xy + cap);                // [cap] their caller ids
+    double2 *s_cc = s_xy + img_pieces;                       // [2][256] the lanes' c-side blocks (top piece, bottom piece)
+    double2 *s_dd = s_cc + 2 * kFanThreads;                  // [2][256] the lanes' diagonal shares
+    int32_t *s_col = (int32_t *)(s_dd + 2 * kFanThreads);    // [256] lane k of a node: the row's k-th column
+    int32_t *s_big = s_col + kFanThreads;                    // [B] rows left to the workgroup: caller id, or -1
+    const int lane = threadIdx.x, k = lane & (kFanLanes - 1), gbase = lane & ~(kFanLanes - 1);
+    // `segs` workgroups share a tile (each stages the whole image and takes B / segs of its row nodes): meshes of few
+    // tiles still fill the chip
+    const int32_t t = blockIdx.x / segs, seg = blockIdx.x % segs;
+    const int32_t lfirst = seg * (B / segs), lend = lfirst + B / segs;
+    // ---- the tile's image: coordinates and caller ids of its owned and halo nodes
+    const int32_t hoff = tile_hoff[t], nh = tile_hoff[t + 1] - hoff;
+    bool in_range = true;
+    for (int32_t l = lane; l < B; l += kFanThreads) {
+        const int64_t gg = (int64_t)t * B + l;
+        s_big[l] = -1;
+        if (gg < N) {
+            const double2 c = xyP[gg];
+            s_xy[l] = c;
+            s_cid[l] = (int32_t)perm[gg];
+            in_range &= coord_in_range(c.x) && coord_in_range(c.y);
+        }
+    }
+    for (int32_t h = lane; h < nh; h += kFanThreads) {
+        const double2 c = halo_xy[hoff + h];
+        s_xy[B + h] = c;
+        s_cid[B + h] = (int32_t)perm[halo_g[hoff + h]];
+        in_range &= coord_in_range(c.x) && coord_in_range(c.y);
+    }
+    const bool sane = __syncthreads_and(in_range ? 1 : 0) != 0;
+    double D[9];
+    stress_strain(nu, youngs, D);
+    const int32_t td = tile_deg[t];
+    const uint32_t *table = ell_asm + tile_off[t];
+    bool any_big = false;
+    constexpr int kStep = kFanThreads / kFanLanes; // nodes per pass
+    // Software pipeline over the passes: while pass n is evaluated, the row pointers and the corner word of pass n + 1 are
+    // in flight, and the row's columns of pass n + 1 are requested at the end of pass n (they need its row pointer) -- they
+    // are only used after the evaluation, for the positions of the finished blocks.  No global latency sits on the path
+    // of a wave; 16 waves per CU cover the rest.
+    struct Row {
+        int32_t i, p, cnt;
+        uint32_t w;
+    };
+    auto fetch = [&](int32_t l) {
+        Row r = {-1, 0, 0, 0xffffffffu};
+        if ((int64_t)t * B + l < N && l < lend) {
+            r.i = s_cid[l];
+            r.p = bptr[r.i];
+            r.cnt = bptr[r.i + 1] - r.p; // 0: a row this rank does not keep (several GPUs)
+            if (k < td) r.w = table[(int64_t)k * B + l];
+        }
+        return r;
+    };
+    Row cur = fetch(lfirst + (lane >> 3));
+    int32_t colk = (cur.cnt > 0 && cur.cnt <= kFanLanes && k < cur.cnt) ? bcol[cur.p + k] : 0x7fffffff;
+    for (int32_t l0 = lfirst; l0 < lend; l0 += kStep) {
+        const int32_t l = l0 + (lane >> 3); // this lane's node inside the tile
+        const Row nxt = fetch(l + kStep);   // pass n + 1: in flight during the evaluation below
+        const int32_t i = cur.i, p = cur.p, cnt = cur.cnt;
+        const uint32_t w = cur.w;
+        const bool live = w != 0xffffffffu;
+        // bit 15: the node cannot be assembled triangle by triangle (every word of the node carries it)
+        const bool fanrow = live && cnt > 0 && cnt <= kFanLanes && !((w >> 15) & 1u);
+        const uint32_t lb = live ? (w & 0xfffu) : 0u, lc = live ? ((w >> 16) & 0xfffu) : 0u;
+        double dgc[4] = {0.0, 0.0, 0.0, 0.0}, kbv[4] = {0.0, 0.0, 0.0, 0.0}, kcv[4] = {0.0, 0.0, 0.0, 0.0};
+        int32_t ib = 0, ic = 0;
+        if (fanrow) {
+            ib = s_cid[lb];
+            ic = s_cid[lc];
+            asm_fan_blocks((int)((w >> 12) & 3u), s_xy[l], s_xy[lb], s_xy[lc], D, thick, sane, dgc, kbv, kcv);
+        }
+        s_col[lane] = colk;
+        s_cc[lane] = make_double2(kcv[0], kcv[1]); // [piece][lane]: consecutive lanes, consecutive 16-byte pieces
+        s_cc[kFanThreads + lane] = make_double2(kcv[2], kcv[3]);
+        s_dd[lane] = make_double2(dgc[0], dgc[1]);
+        s_dd[kFanThreads + lane] = make_double2(dgc[2], dgc[3]);
+        const unsigned long long livemask = __ballot(fanrow ? 1 : 0);
+        wave_lds_sync();
+        if (fanrow) {
+            const int4 c03 = *(const int4 *)(s_col + gbase), c47 = *(const int4 *)(s_col + gbase + 4);
+            const int32_t gc[8] = {c03.x, c03.y, c03.z, c03.w, c47.x, c47.y, c47.z, c47.w};
+            double *r0 = kval + 4 * (int64_t)p, *r1 = r0 + 2 * cnt;
+            int kb_pos = 0, kc_pos = 0; // positions of b and c among the row's ascending columns
+#pragma unroll
+            for (int j = 0; j < kFanLanes; ++j) {
+                kb_pos += gc[j] < ib ? 1 : 0;
+                kc_pos += gc[j] < ic ? 1 : 0;
+            }
+            double t0 = 0.0 + kbv[0], t1 = 0.0 + kbv[1], t2 = 0.0 + kbv[2], t3 = 0.0 + kbv[3];
+            if (w >> 31) { // the other side of the edge a-b: the triangle whose c is this one's b
+                const int pj = gbase + (int)((w >> 28) & 7u);
+                const double2 q0 = s_cc[pj], q1 = s_cc[kFanThreads + pj];
+                t0 = t0 + q0.x;
+                t1 = t1 + q0.y;
+                t2 = t2 + q1.x;
+                t3 = t3 + q1.y;
+            }
+            *(double2 *)(r0 + 2 * kb_pos) = make_double2(t0, t1);
+            *(double2 *)(r1 + 2 * kb_pos) = make_double2(t2, t3);
+            if ((w >> 14) & 1u) { // c has no b-side triangle: the open end of a boundary fan
+                *(double2 *)(r0 + 2 * kc_pos) = make_double2(0.0 + kcv[0], 0.0 + kcv[1]);
+                *(double2 *)(r1 + 2 * kc_pos) = make_double2(0.0 + kcv[2], 0.0 + kcv[3]);
+            }
+            if (k == 0) { // the diagonal: the triangles' shares in ascending element order (slot order), from 0.0
+                const unsigned mine = (unsigned)((livemask >> (gbase & 63)) & 0xffull);
+                int kd = 0;
+                double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+                for (int j = 0; j < kFanLanes; ++j) {
+                    kd += gc[j] < i ? 1 : 0;
+                    if ((mine >> j) & 1u) {
+                        const double2 q0 = s_dd[gbase + j], q1 = s_dd[kFanThreads + gbase + j];
+                        d0 += q0.x;
+                        d1 += q0.y;
+                        d2 += q1.x;
+                        d3 += q1.y;
+                    }
+                }
+                *(double2 *)(r0 + 2 * kd) = make_double2(d0, d1);
+                *(double2 *)(r1 + 2 * kd) = make_double2(d2, d3);
+            }
+        } else if (cnt > 0 && k == 0 && i >= 0) {
+            s_big[l] = i;
+            any_big = true;
+        }
+        cur = nxt;
+        colk = (cur.cnt > 0 && cur.cnt <= kFanLanes && k < cur.cnt) ? bcol[cur.p + k] : 0x7fffffff;
+    }
+    // rows the fan scheme did not take: the whole workgroup, one thread per block, k_assemble_rows arithmetic
+    if (!__syncthreads_or(any_big ? 1 : 0)) return;
+    for (int m = lfirst; m < lend; ++m) {
+        const int32_t ib = s_big[m];
+        if (ib < 0) continue; // uniform
+        const int64_t gb_ = (int64_t)t * B + m;
+        const int32_t pb = bptr[ib], cb = bptr[ib + 1] - pb;
+        for (int kpos = lane; kpos < cb; kpos += kFanThreads) {
+            const int32_t j = bcol[pb + kpos];
+            double k00 = 0.0, k01 = 0.0, k10 = 0.0, k11 = 0.0;
+            for (int32_t q = inc_off[gb_]; q < inc_off[gb_ + 1]; ++q) {
+                const uint32_t v = inc[q];
+                const uint32_t e = v / 3u;
+                const int a = (int)(v - 3u * e);
+                const int32_t n0 = conn[3 * (int64_t)e], n1 = conn[3 * (int64_t)e + 1], n2 = conn[3 * (int64_t)e + 2];
+                if (n0 != j && n1 != j && n2 != j) continue;
+                const double2 v0 = xy[n0], v1 = xy[n1], v2 = xy[n2];
+                const int32_t nn[3] = {n0, n1, n2};
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    if (nn[b] != j) continue;
+                    double c00, c01, c10, c11;
+                    ke_block(v0, v1, v2, a, b, D, thick, c00, c01, c10, c11);
+                    k00 += c00;
+                    k01 += c01;
+                    k10 += c10;
+                    k11 += c11;
+                }
+            }
+            double *r0 = kval + 4 * (int64_t)pb + 2 * kpos;
+            double *r1 = kval + 4 * (int64_t)pb + 2 * cb + 2 * kpos;
+            r0[0] = k00;
+            r0[1] = k01;
+            r1[0] = k10;
+            r1[1] = k11;
+        }
+    }
+}
+
+static int32_t asm_img_pieces(int32_t cap) { return (cap * 20 + 15) / 16; } // 16-byte pieces of the staged image
+
+size_t assemble_ctiles_lds(int32_t B, int32_t cap)
+{
+    return (size_t)asm_img_pieces(cap) * 16 + (size_t)kFanThreads * (64 + 4) + (size_t)B * 4;
+}
+
+bool assemble_ctiles(const int32_t *bcol, const int32_t *bptr, const uint32_t *perm, const double *xyP,
+                     const double *halo_xy, const int32_t *halo_g, const int32_t *tile_hoff, const int32_t *tile_deg,
+                     const int64_t *tile_off, const uint32_t *ell_asm, const int32_t *inc_off, const uint32_t *inc,
+                     const int32_t *conn, const double *xy, int64_t N, int32_t B, int32_t T, int32_t cap, double nu,
+                     double youngs, double thick, double *kval, hipStream_t s)
+{
+    const size_t lds = assemble_ctiles_lds(B, cap);
+    if ((B != 256 && B != 512) || cap > 4096 || lds > 64 * 1024) return false; // 12-bit local ids; the image fits the LDS
+    const int32_t img = asm_img_pieces(cap);
+    // workgroups per tile: at least ~4 per CU on small meshes (measured at 982 tiles: 1 per tile 64.2 us, 2: 66.5, 4: 70.2)
+    int32_t segs = 1;
+    while ((int64_t)T * segs < 1024 && B / (2 * segs) >= kFanThreads / kFanLanes) segs *= 2;
+    if (const char *e = getenv("MAG_TUNE_ASM_SEGS")) segs = std::max(1, std::min(atoi(e), B / (kFanThreads / kFanLanes)));
+    if (B == 256)
+        k_assemble_fan<256><<<T * segs, kFanThreads, lds, s>>>(
+            bcol, bptr, perm, (const double2 *)xyP, (const double2 *)halo_xy, halo_g, tile_hoff, tile_deg, tile_off,
+            ell_asm, inc_off, inc, conn, (const double2 *)xy, N, cap, img, segs, nu, youngs, thick, kval);
+    else
+        k_assemble_fan<512><<<T * segs, kFanThreads, lds, s>>>(
+            bcol, bptr, perm, (const double2 *)xyP, (const double2 *)halo_xy, halo_g, tile_hoff, tile_deg, tile_off,
+            ell_asm, inc_off, inc, conn, (const double2 *)xy, N, cap, img, segs, nu, youngs, thick, kval);
+    return true;
 }
 
 // Opt-in preconditioner (the reference has none, solver.rs:142): the node-diagonal 2x2 blocks of

@@ -550,7 +550,8 @@ constexpr int persist_npt(int threads) { return threads == 768 ? 3 : 4; } // nod
 #else
 #define MAG_STAMP(k)
 #endif
-constexpr int kStampFrom = 200, kStampTo = 1200, kStampPhases = 8;
+[[maybe_unused]] constexpr int kStampFrom = 200, kStampTo = 1200;
+constexpr int kStampPhases = 8;
 
 template <int B, bool MG, int THREADS>
 __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)

@@ -322,7 +322,8 @@ __device__ inline uint32_t local_id(int32_t g, int32_t base, int32_t B, const in
 __global__ void __launch_bounds__(256) k_fill_ell16(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn,
                                                     const int32_t *iperm, const int32_t *tile_deg,
                                                     const int64_t *tile_off, const int32_t *tile_hoff,
-                                                    const int32_t *halo_g, int64_t N, int32_t B, uint32_t *ell)
+                                                    const int32_t *halo_g, int64_t N, int32_t B, uint32_t *ell,
+                                                    uint32_t *ell_asm)
 {
     const int32_t t = blockIdx.x;
     const int32_t td = tile_deg[t];
@@ -330,6 +331,9 @@ __global__ void __launch_bounds__(256) k_fill_ell16(const int32_t *inc_off, cons
     const int32_t *hl = halo_g + tile_hoff[t];
     const int32_t nh = tile_hoff[t + 1] - tile_hoff[t];
     uint32_t *dst = ell + tile_off[t];
+    // the assembly's copy (k_assemble_fan, exact.hip): the same ids with the node's corner label and the pairing of the
+    // node's triangles in the spare bits; it stays as written here, while `ell` is rewritten into ring form by k_ring16
+    uint32_t *dst_asm = ell_asm ? ell_asm + tile_off[t] : nullptr;
     for (int l = threadIdx.x; l < B; l += 256) {
         const int64_t i = (int64_t)base + l;
         int32_t o = 0, d = 0;
@@ -349,14 +353,65 @@ __global__ void __launch_bounds__(256) k_fill_ell16(const int32_t *inc_off, cons
             }
             dst[(int64_t)k * B + l] = w;
         }
+        if (!dst_asm) continue;
+        // The assembly's words: lb | label << 12 | flags << 14 | lc << 16 | partner << 28 | has_partner << 31, where the
+        // PARTNER of triangle k is the triangle of the same node whose c is k's b (the other side of the edge a-b) and
+        // flag bit 0 = "k's c is nobody's b" (open end of a fan), bit 1 = the node cannot be assembled triangle by
+        // triangle (an element listing a node twice, an edge with three or more triangles, more than eight triangles).
+        // Second pass over the row just written (ids back from `dst`: still in pre-ring form, this thread's own stores).
+        // (rows of up to eight triangles are held in registers for this; longer ones are flagged and never paired)
+        uint32_t ws[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ws[k] = (k < d && k < td) ? dst[(int64_t)k * B + l] : 0xffffffffu;
+        bool odd = d > 8;
+        uint32_t pjs = 0, has = 0, openc = 0; // per triangle: partner (3 bits each), has a partner, its c is nobody's b
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (ws[k] == 0xffffffffu) continue;
+            const uint32_t lbk = ws[k] & 0xffffu, lck = ws[k] >> 16;
+            int npb = 0, npc = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (ws[j] == 0xffffffffu) continue;
+                if ((ws[j] >> 16) == lbk) {
+                    ++npb;
+                    pjs = (pjs & ~(7u << (3 * k))) | ((uint32_t)j << (3 * k));
+                }
+                npc += (ws[j] & 0xffffu) == lck ? 1 : 0;
+            }
+            has |= (npb > 0 ? 1u : 0u) << k;
+            openc |= (npc == 0 ? 1u : 0u) << k;
+            odd |= lbk == lck || lbk == (uint32_t)l || lck == (uint32_t)l || npb > 1 || npc > 1;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k >= td) break;
+            uint32_t wa = 0xffffffffu;
+            if (ws[k] != 0xffffffffu) {
+                const uint32_t v = inc[o + k];
+                const uint32_t c = v - 3u * (v / 3u);
+                wa = (ws[k] & 0xffffu) | (c << 12) | (((openc >> k) & 1u) << 14) | ((odd ? 1u : 0u) << 15) |
+                     ((ws[k] >> 16) << 16) | (((pjs >> (3 * k)) & 7u) << 28) | (((has >> k) & 1u) << 31);
+            }
+            dst_asm[(int64_t)k * B + l] = wa;
+        }
+        for (int k = 8; k < td; ++k) { // a node of more than eight triangles is flagged (odd): only ids and label matter
+            uint32_t wa = 0xffffffffu;
+            if (k < d) {
+                const uint32_t v = inc[o + k];
+                const uint32_t wk = dst[(int64_t)k * B + l];
+                wa = (wk & 0xffffu) | ((v - 3u * (v / 3u)) << 12) | (1u << 15) | ((wk >> 16) << 16);
+            }
+            dst_asm[(int64_t)k * B + l] = wa;
+        }
     }
 }
 
 void fill_ell16(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn, const int32_t *iperm,
                 const int32_t *tile_deg, const int64_t *tile_off, const int32_t *tile_hoff, const int32_t *halo_g,
-                int64_t N, int32_t B, int32_t T, uint32_t *ell, hipStream_t s)
+                int64_t N, int32_t B, int32_t T, uint32_t *ell, uint32_t *ell_asm, hipStream_t s)
 {
-    k_fill_ell16<<<T, 256, 0, s>>>(inc_off, inc, conn, iperm, tile_deg, tile_off, tile_hoff, halo_g, N, B, ell);
+    k_fill_ell16<<<T, 256, 0, s>>>(inc_off, inc, conn, iperm, tile_deg, tile_off, tile_hoff, halo_g, N, B, ell, ell_asm);
 }
 
 // Ring form of the tile-local table.  fill_ell16 leaves one word (lb | lc << 16) per incident triangle (a, b, c);

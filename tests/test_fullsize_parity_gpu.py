@@ -82,3 +82,21 @@ def test_plate100k_against_the_live_oracle(built, variant):
     k = p.u_known == 1
     assert np.array_equal(out["f"][~k], p.f_in[~k])
     assert rel(out["f"][k], ref["f"][k]) <= TOL_DERIVED
+
+
+@pytest.mark.parametrize("name", ["hole1m", "plate4m"])
+def test_assembled_matrix_at_baseline_size_is_the_oracles_bit_for_bit(built, name, monkeypatch):
+    """K (solver.rs:290-331) of the BASELINE meshes, assembled from the CG tiles (k_assemble_ctile, the default) and by
+    round 2's kernel on caller-numbered gathers (MAG_TUNE_ASSEMBLY=tiles): pattern and values equal to the oracle's
+    sparse restatement bit for bit (the oracle needs ~1-3 s for the assembly alone, no solve)."""
+    import oracle
+    p = meshgen.baseline_problem(name)
+    K = oracle.assemble_sparse(p.xy_flat, p.conn_flat, p.poisson_ratio, p.youngs_modulus, p.part_thickness, threads=8)
+    for how in (None, "tiles"):
+        if how:
+            monkeypatch.setenv("MAG_TUNE_ASSEMBLY", how)
+        with Context(device=0) as c:
+            c.upload_problem(p)
+            rowptr, col, val = c.assemble_csr()
+        assert np.array_equal(rowptr.astype(np.int64), K.rowptr) and np.array_equal(col, K.col), how
+        assert np.array_equal(val, K.val), how

@@ -355,10 +355,15 @@ def test_assembly_fast_paths_at_their_row_length_limits(built, valence, monkeypa
     A, bo = oracle.reduce_system(K, p.u_known, p.u_in, p.f_in)
     assert np.diff(K.rowptr).max() == 2 * (valence + 1)
     got = {}
-    for how in ("incidence", "sort"):
+    # the assembly fed from the CG tiles (default) at both tile sizes, round 2's kernel on caller-numbered gathers, and the
+    # sort-based pattern
+    for how in ("incidence", "ctile512", "tiles", "sort"):
         if how == "sort":
+            monkeypatch.delenv("MAG_TUNE_ASSEMBLY")
             monkeypatch.setenv("MAG_TUNE_PATTERN_SORT", "1")
-        with Context(device=0) as c:
+        if how == "tiles":
+            monkeypatch.setenv("MAG_TUNE_ASSEMBLY", "tiles")
+        with Context(device=0, tile_nodes=512 if how == "ctile512" else 0) as c:
             c.upload_problem(p)
             rowptr, col, val = c.assemble_csr()
             rp, cf, vf, b = c.reduce_system()
@@ -367,7 +372,30 @@ def test_assembly_fast_paths_at_their_row_length_limits(built, valence, monkeypa
         assert np.array_equal(rp.astype(np.int64), A.rowptr) and np.array_equal(cf, A.col) and np.array_equal(vf, A.val)
         assert np.array_equal(b, bo)
         got[how] = val
-    assert np.array_equal(got["incidence"], got["sort"])
+    assert np.array_equal(got["incidence"], got["sort"]) and np.array_equal(got["incidence"], got["tiles"])
+
+
+@pytest.mark.parametrize("how", [None, "tiles"])
+def test_assembly_of_an_element_that_lists_a_node_twice(built, how, monkeypatch):
+    """solver.rs:299-325 adds an element's nine blocks in label order wherever they land; an element (n0, n1, n0) lands two
+    of a row's three blocks on the SAME entry (and has zero area: its contributions are inf / NaN, as in the reference).
+    The tile kernels take their label-ordered path for it; everything else in K stays bit-identical to the oracle."""
+    if how:
+        monkeypatch.setenv("MAG_TUNE_ASSEMBLY", how)
+    m = meshgen.plate(9)
+    conn = m.conn.copy()
+    conn[17, 2] = conn[17, 0]
+    conn[40, 1] = conn[40, 2]
+    p = meshgen.config_fixed_left_pull_right(meshgen.Mesh(m.xy, conn, "degenerate"))
+    K = oracle.assemble_sparse(p.xy_flat, p.conn_flat, p.poisson_ratio, p.youngs_modulus, p.part_thickness)
+    with Context(device=0) as c:
+        c.upload_problem(p)
+        rowptr, col, val = c.assemble_csr()
+    assert np.array_equal(rowptr.astype(np.int64), K.rowptr) and np.array_equal(col, K.col)
+    bad = ~np.isfinite(K.val)
+    assert bad.any() and not bad.all()
+    assert np.array_equal(~np.isfinite(val), bad)              # the same entries are poisoned
+    assert np.array_equal(val[~bad], K.val[~bad])              # and every other entry has the oracle's bits
 
 
 @pytest.mark.parametrize("which,scale", [("hole1m", 1.0), ("plate100k", 1.0), ("plate4m", 1.0)])
@@ -774,9 +802,9 @@ def test_timing_hooks_report_plausible_launch_times(built):
         cold_it, cold_mv = c.time_operator(10), c.time_spmv(10)   # straight after the upload: symbolic phase only
         assert cold_it > 0 and cold_mv > 0
         c.run()
-        us_it = c.time_operator(50) * 1e3
+        us_it = min(c.time_operator(50) for _ in range(3)) * 1e3   # best of three: a busy box must not fail the test
         assert 0.5 < cold_it * 1e3 / us_it < 2.0
-        us_mv = c.time_spmv(50) * 1e3
+        us_mv = min(c.time_spmv(50) for _ in range(3)) * 1e3
         u1 = c.download()[0]
         c.run()                                  # the hooks run on scratch state: a later solve is unaffected
         assert np.array_equal(c.download()[0], u1)
