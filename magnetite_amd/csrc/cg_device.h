@@ -147,4 +147,94 @@ __device__ inline void ring_walk_uniform(const uint32_t (&w)[NW], const uint32_t
     }
 }
 
+// The same walk with the triangles' weights c0 / (2A) held in registers (the on-chip CG kernel): 2A depends on the
+// coordinates only, so the cross product, the v_rcp_f64, its two Newton steps and the scaling -- 8 of the ~48
+// instructions of a ring step, the only quarter-rate one among them -- are paid once per solve instead of once per
+// iteration, by ring_weights() below with the very operations ring_walk_uniform uses (same bits).  The break bit is
+// folded into the weight (0 for an entry that closes no triangle: its bracket is finite, 0 x finite adds nothing), so
+// the per-entry selects go as well.  NC weights per node (a closed fan of valence 6 has 6 triangles); triangles beyond
+// NC are evaluated as before.
+template <int NW, int NC>
+__device__ inline void ring_weights(const uint32_t (&w)[NW], int32_t nent, const double2 *s_xy, const double2 ca, double c0,
+                                    double (&wgt)[NC])
+{
+    double2 pd;
+    auto entry = [&](int k) { return (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu); };
+    {
+        const double2 cxy = s_xy[entry(0) & 0xfffu];
+        pd = make_double2(cxy.x - ca.x, cxy.y - ca.y);
+    }
+#pragma unroll
+    for (int k = 1; k <= NC; ++k) {
+        wgt[k - 1] = 0.0;
+        if (k < nent && k < 2 * NW) {
+            const uint32_t e = entry(k);
+            const double2 cxy = s_xy[e & 0xfffu];
+            const double2 d = make_double2(cxy.x - ca.x, cxy.y - ca.y);
+            const double twoA = pd.x * d.y - d.x * pd.y;
+            if (!(e & 0x8000u)) wgt[k - 1] = c0 * fast_rcp(twoA);
+            pd = d;
+        }
+    }
+}
+
+template <class V2, class R>
+__device__ inline void fan_force_w(const V2 db, const V2 ub, const V2 dc, const V2 uc, R wt, R nu, R h, R &fx, R &fy)
+{
+    const R ba = db.y - dc.y, ga = dc.x - db.x;
+    const R ex = dc.y * ub.x - db.y * uc.x;
+    const R ey = db.x * uc.y - dc.x * ub.y;
+    const R g = (dc.y * ub.y - dc.x * ub.x) + (db.x * uc.x - db.y * uc.y);
+    const R sx = ex + nu * ey, sy = nu * ex + ey, tq = h * g;
+    fx += wt * (ba * sx + ga * tq);
+    fy += wt * (ga * sy + ba * tq);
+}
+
+template <int NW, int NC>
+__device__ inline void ring_walk_cached(const uint32_t (&w)[NW], const uint32_t *more, int32_t stride, int32_t nent,
+                                        const double2 *s_xy, const double2 *s_p, const double2 ca, const double2 pa,
+                                        double c0, double nu, double h, const double (&wgt)[NC], double &fx, double &fy)
+{
+    double2 pd, pu;
+    auto entry = [&](int k) { return (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu); };
+    auto gather = [&](uint32_t e, double2 &d, double2 &u) {
+        const uint32_t id = e & 0xfffu;
+        const double2 cxy = s_xy[id], cp = s_p[id];
+        d = make_double2(cxy.x - ca.x, cxy.y - ca.y);
+        u = make_double2(cp.x - pa.x, cp.y - pa.y);
+    };
+    gather(entry(0), pd, pu);
+#pragma unroll
+    for (int k = 1; k < 2 * NW; ++k)
+        if (k < nent) { // nent: a scalar
+            const uint32_t e = entry(k);
+            double2 d, u;
+            gather(e, d, u);
+            if (k <= NC) {
+                fan_force_w<double2, double>(pd, pu, d, u, wgt[k - 1], nu, h, fx, fy);
+            } else {
+                double dfx = 0.0, dfy = 0.0;
+                fan_force<double2, double>(pd, pu, d, u, c0, nu, h, dfx, dfy);
+                const bool closes = !(e & 0x8000u);
+                fx += closes ? dfx : 0.0;
+                fy += closes ? dfy : 0.0;
+            }
+            pd = d;
+            pu = u;
+        }
+    for (int32_t k = 2 * NW; k < nent; ++k) {
+        const uint32_t ww = more[(int64_t)(k >> 1) * stride];
+        const uint32_t e = (k & 1) ? (ww >> 16) : (ww & 0xffffu);
+        double2 d, u;
+        gather(e, d, u);
+        double dfx = 0.0, dfy = 0.0;
+        fan_force<double2, double>(pd, pu, d, u, c0, nu, h, dfx, dfy);
+        const bool closes = !(e & 0x8000u);
+        fx += closes ? dfx : 0.0;
+        fy += closes ? dfy : 0.0;
+        pd = d;
+        pu = u;
+    }
+}
+
 } // namespace magk

@@ -533,6 +533,12 @@ constexpr int kPersistRegs = 5; // ring words in registers per node: 10 entries,
 #endif
 // ring entries walked as straight-line blocks: 1 .. BLOCK - 1 and BLOCK .. BLOCK2 - 1 (cg_device.h, ring_walk_uniform)
 constexpr int kPersistBlock = MAG_PERSIST_BLOCK, kPersistBlock2 = MAG_PERSIST_BLOCK2;
+#ifndef MAG_PERSIST_WEIGHTS
+#define MAG_PERSIST_WEIGHTS 6
+#endif
+// triangle weights c0 / (2A) kept in registers per node (cg_device.h, ring_walk_cached); 0: recomputed every iteration.
+// The multi-GPU instantiation has no registers to spare for them (237 VGPRs without).
+constexpr int kPersistWeights = MAG_PERSIST_WEIGHTS;
 constexpr int kPersistNh = 2;   // halo entries per thread: a workgroup's tiles may carry 2 * THREADS halo nodes in all
 constexpr int persist_npt(int threads) { return threads == 768 ? 3 : 4; } // nodes per lane
 
@@ -672,6 +678,22 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         return;
 
     const double c0 = P.c0, nu = P.nu, h = P.h;
+    // iteration-invariant part of the ring walks: the triangles' weights c0 / (2A), once per solve (the exchange above
+    // ended with a workgroup barrier: the coordinates are staged)
+    constexpr int NCW = (!MG && kPersistWeights > 0) ? kPersistWeights : 1;
+    constexpr bool CACHED = !MG && kPersistWeights > 0;
+    double wgt[NPT][NCW];
+    if (CACHED) {
+#pragma unroll
+        for (int s = 0; s < NPT; ++s) {
+#pragma unroll
+            for (int c = 0; c < NCW; ++c) wgt[s][c] = 0.0;
+            if (!(flags[s] & 8)) continue;
+            const double2 *xy = t_xy(s);
+            const int32_t nent = __builtin_amdgcn_readfirstlane(ent[s]);
+            if (nent > 0) ring_weights<kPersistRegs, NCW>(w[s], nent, xy, xy[t_lt(s)], c0, wgt[s]);
+        }
+    }
     double target = P.tol, bb = 0.0;
     long long j = 0;
     int verdict = 0; // 1 converged, 2 iteration cap, 3 non-finite
@@ -766,9 +788,14 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             double fx = 0.0, fy = 0.0;
             {
                 const int32_t nent = __builtin_amdgcn_readfirstlane(ent[s]); // one tile per wave: a scalar
-                if (nent > 0)
-                    ring_walk_uniform<kPersistRegs, kPersistBlock, kPersistBlock2>(w[s], P.ell16 + ell_off[s], B, nent, xy, pim, ca, pa, c0, nu, h, fx,
-                                                    fy);
+                if (nent > 0) {
+                    if (CACHED)
+                        ring_walk_cached<kPersistRegs, NCW>(w[s], P.ell16 + ell_off[s], B, nent, xy, pim, ca, pa, c0, nu,
+                                                            h, wgt[s], fx, fy);
+                    else
+                        ring_walk_uniform<kPersistRegs, kPersistBlock, kPersistBlock2>(w[s], P.ell16 + ell_off[s], B, nent,
+                                                                                      xy, pim, ca, pa, c0, nu, h, fx, fy);
+                }
             }
             if ((flags[s] & 1) || !(flags[s] & 16)) fx = 0.0;
             if ((flags[s] & 2) || !(flags[s] & 16)) fy = 0.0;

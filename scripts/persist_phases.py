@@ -2,9 +2,10 @@
 
 Runs the 1M-triangle benchmark solve (BASELINE config 3, 5389 iterations) with the DIAGNOSTIC build of the library
 (`make -C magnetite_amd/csrc stamps` -> libmagnetite_hip_stamps.so: lane 0 of every workgroup reads the 100 MHz constant
-clock, s_memrealtime, at the phase boundaries of iterations 200..1199 and adds the differences up) for both workgroup
-shapes (512 threads x 4 nodes per lane, 768 x 3), and the same solves with the product build (no stamp executes) for
-the un-instrumented time per iteration.  One process per run: the shape is read once per process.
+clock, s_memrealtime, at the phase boundaries of iterations 200..1199 and adds the differences up) and the
+same solves with the product build (no stamp executes) for the un-instrumented time per iteration.  `--shapes 512,768` also
+runs the 768 x 3 workgroup shape -- only in libraries built with -DMAG_PERSIST_768 (round 3's record,
+profiles/r03_persist_phases.json, has both: 768 was slower and is not instantiated in the product).
 
     python scripts/persist_phases.py [out.json]        (on the GPU box; default profiles/r03_persist_phases.json)
 """
@@ -43,11 +44,13 @@ def run(workload, threads, stamps_file):
 
 
 def main():
-    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r03_persist_phases.json")
+    args = [a for a in sys.argv[1:] if not a.startswith("--shapes")]
+    shapes = [int(x) for a in sys.argv[1:] if a.startswith("--shapes") for x in a.split("=")[1].split(",")] or [512]
+    out_path = args[0] if args else os.path.join(ROOT, "profiles", "r03_persist_phases.json")
     out = {"what": __doc__.strip().splitlines()[0], "clock": "s_memrealtime, 100 MHz (10 ns ticks)",
            "iterations_stamped": "200..1199 of each solve, lane 0 of every workgroup", "runs": []}
     for workload in ("hole1m", "plate100k"):
-        for threads in (512, 768):
+        for threads in shapes:
             plain = run(workload, threads, None)
             f = f"/tmp/persist_stamps_{workload}_{threads}.csv"
             st = run(workload, threads, f)
