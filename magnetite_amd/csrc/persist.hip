@@ -121,8 +121,12 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
     // full round trip.  Two fixed s_sleep instructions, re-tuned in round 2 on one box (us per iteration at 1M triangles):
     // 10+10 10.89, 12+12 10.85, 14+14 10.79, 16+8 10.85, 16+16 10.62, 18+14 10.58, 20+20 10.67, 24+24 10.86; one
     // s_sleep(32) 10.74, one s_sleep(40) 10.79; the same 40 units as a run-time loop of ten s_sleep(4) 10.87.
-    __builtin_amdgcn_s_sleep(18);
-    __builtin_amdgcn_s_sleep(14);
+#ifndef MAG_PERSIST_SLEEP1
+#define MAG_PERSIST_SLEEP1 18
+#define MAG_PERSIST_SLEEP2 14
+#endif
+    __builtin_amdgcn_s_sleep(MAG_PERSIST_SLEEP1);
+    if (MAG_PERSIST_SLEEP2 > 0) __builtin_amdgcn_s_sleep(MAG_PERSIST_SLEEP2);
 #ifdef MAG_PERSIST_STAMPS
     if (stamp) stamp[0] = __builtin_amdgcn_s_memrealtime();
 #endif
