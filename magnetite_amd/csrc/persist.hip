@@ -130,6 +130,47 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
 #ifdef MAG_PERSIST_STAMPS
     if (stamp) stamp[0] = __builtin_amdgcn_s_memrealtime();
 #endif
+#ifndef MAG_PERSIST_POLL
+#define MAG_PERSIST_POLL 1
+#endif
+#if MAG_PERSIST_POLL
+    // Every WAVE polls for what its own lanes still miss and the workgroup meets once, when every wave has everything:
+    // a workgroup barrier per sweep (round 1-2) made every sweep as slow as the slowest wave's loads and started the next
+    // one only after all of them.
+    bool wave_ok = false;
+    unsigned spins = 0;
+    for (; spins < P.spin_limit; ++spins) {
+        bool ok = true;
+        if (!have_rec) {
+            double2 v;
+            have_rec = get_granules(recb, 64u * (uint32_t)grid, 32u * (uint32_t)tid, epoch, v);
+            if (have_rec) s_rec[tid] = v;
+            ok = have_rec;
+        }
+#pragma unroll
+        for (int s = 0; s < NH; ++s)
+            if (!have_h[s]) {
+                have_h[s] = get_granules(qbase, 32u * (uint32_t)P.N, 32u * (uint32_t)hg[s], epoch, hq[s]);
+                ok &= have_h[s];
+            }
+        if (__all(ok ? 1 : 0)) {
+            wave_ok = true;
+            break;
+        }
+        if ((spins & 255u) == 255u) { // somebody gave up: do not wait for a grid that will never be complete
+            const unsigned dead = (tid & 63) == 0 ? __hip_atomic_load(tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            if (__any(dead != 0u ? 1 : 0)) break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    done = __syncthreads_and(wave_ok ? 1 : 0) != 0; // also: s_rec complete
+#ifdef MAG_PERSIST_STAMPS
+    if (stamp) {
+        stamp[1] = __builtin_amdgcn_s_memrealtime();
+        stamp[2] = spins + 1;
+    }
+#endif
+#else
     for (unsigned spins = 0; spins < P.spin_limit; ++spins) {
         bool ok = true;
         if (!have_rec) {
@@ -161,13 +202,14 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
         }
         __builtin_amdgcn_s_sleep(1);
     }
+    __syncthreads(); // s_rec complete
+#endif
     if (!done) {
         if (tid == 0) __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return false;
     }
     // every workgroup sums the same values in the same order (four records per lane, then the lanes): same bits
     // everywhere
-    __syncthreads(); // s_rec complete
     if (tid < 64) {
         double S[4] = {0.0, 0.0, 0.0, 0.0};
         for (int m = tid; m < grid; m += 64) {
