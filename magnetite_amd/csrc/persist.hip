@@ -726,8 +726,12 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
     const double c0 = P.c0, nu = P.nu, h = P.h;
     // iteration-invariant part of the ring walks: the triangles' weights c0 / (2A), once per solve (the exchange above
     // ended with a workgroup barrier: the coordinates are staged)
-    constexpr int NCW = (!MG && kPersistWeights > 0) ? kPersistWeights : 1;
-    constexpr bool CACHED = !MG && kPersistWeights > 0;
+#ifndef MAG_PERSIST_WEIGHTS_MG
+#define MAG_PERSIST_WEIGHTS_MG 0
+#endif
+    constexpr int kW = MG ? MAG_PERSIST_WEIGHTS_MG : kPersistWeights;
+    constexpr int NCW = kW > 0 ? kW : 1;
+    constexpr bool CACHED = kW > 0;
     double wgt[NPT][NCW];
     if (CACHED) {
 #pragma unroll
