@@ -105,13 +105,12 @@ fn dump_reference() {
         *k += known_forces[i].unwrap();
     }
     let n = unknown.nrows();
+    // the same exact-zero drop and row-major push order as solver.rs:126-137 (the CSR's column order follows from it)
     let mut coo: CooMatrix<f64> = CooMatrix::new(n, n);
-    for row in 0..n {
-        for col in 0..n {
-            let k = unknown[(row, col)];
-            if k != 0.0 {
-                coo.push(row, col, k)
-            }
+    for (r, c) in (0..n).flat_map(|r| (0..n).map(move |c| (r, c))) {
+        let entry = unknown[(r, c)];
+        if entry != 0.0 {
+            coo.push(r, c, entry);
         }
     }
     let csr: CsrMatrix<f64> = CsrMatrix::from(&coo);
