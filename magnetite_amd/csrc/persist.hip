@@ -582,6 +582,9 @@ constexpr int kPersistBlock = MAG_PERSIST_BLOCK, kPersistBlock2 = MAG_PERSIST_BL
 #ifndef MAG_PERSIST_WEIGHTS
 #define MAG_PERSIST_WEIGHTS 6
 #endif
+#ifndef MAG_PERSIST_PRIO
+#define MAG_PERSIST_PRIO 3 // waves 4-7 (the arbitration losers of their SIMDs) take priority for their last two node slots: 9.55 -> 9.21 us
+#endif
 // triangle weights c0 / (2A) kept in registers per node (cg_device.h, ring_walk_cached); 0: recomputed every iteration.
 // The multi-GPU instantiation has no registers to spare for them (237 VGPRs without).
 constexpr int kPersistWeights = MAG_PERSIST_WEIGHTS;
@@ -793,6 +796,11 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         const double beta = (rr + 2.0 * alpha * S2 + alpha * alpha * S3) / rr;
 
         // ---- vector updates: r in registers, p and x in LDS, halo copies in LDS (their q from the publishers)
+#if MAG_PERSIST_PRIO == 11
+        if ((tid >> 8) & 1) __builtin_amdgcn_s_setprio(1);
+#elif MAG_PERSIST_PRIO == 12
+        if (!((tid >> 8) & 1)) __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int s = 0; s < NPT; ++s) {
             if (!(flags[s] & 8)) continue;
@@ -822,6 +830,9 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
                 hbase[2 * cap + maxh] = hpv;
                 hbase[cap + B] = hpv;
             }
+#if MAG_PERSIST_PRIO == 11 || MAG_PERSIST_PRIO == 12
+        __builtin_amdgcn_s_setprio(0);
+#endif
         MAG_STAMP(0) // scalars + vector updates issued
         __syncthreads();
         MAG_STAMP(1) // ... landed in LDS for everybody (workgroup barrier)
@@ -831,6 +842,33 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         for (int c = 0; c < 4; ++c) acc[c] = 0.0;
 #pragma unroll
         for (int s = 0; s < NPT; ++s) {
+#if MAG_PERSIST_PRIO == 1
+            // the two waves of a SIMD take turns at the higher priority, one node slot each: both finish their walks
+            // together instead of the older one 2 us ahead of a partner that then runs alone
+            if ((((tid >> 8) & 1) ^ (s & 1)) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#elif MAG_PERSIST_PRIO == 2
+            if ((((tid >> 8) & 1) ^ ((s >> 1) & 1)) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#elif MAG_PERSIST_PRIO == 3
+            // the younger half (waves 4-7) is the arbitration loser: priority for its LAST two node slots only
+            if (((tid >> 8) & 1) && s >= NPT / 2) __builtin_amdgcn_s_setprio(1);
+#elif MAG_PERSIST_PRIO == 4
+            if (((tid >> 8) & 1) && s >= 1) __builtin_amdgcn_s_setprio(1);
+#elif MAG_PERSIST_PRIO == 5
+            if (((tid >> 8) & 1) && s >= NPT - 1) __builtin_amdgcn_s_setprio(1);
+#elif MAG_PERSIST_PRIO == 6
+            if ((tid >> 8) & 1) __builtin_amdgcn_s_setprio(1);
+#elif MAG_PERSIST_PRIO == 7
+            if ((tid >> 8) & 1) { if (s >= NPT / 2) __builtin_amdgcn_s_setprio(1); }
+            else { if (s < NPT / 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#elif MAG_PERSIST_PRIO == 8
+            if (((tid >> 8) & 1) && s >= NPT / 2) __builtin_amdgcn_s_setprio(2);
+#elif MAG_PERSIST_PRIO == 9
+            if ((tid >> 8) & 1) { if (s < NPT / 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#elif MAG_PERSIST_PRIO == 10
+            if ((tid >> 8) & 1) { if (s == 1 || s == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#elif MAG_PERSIST_PRIO == 11 || MAG_PERSIST_PRIO == 12
+            if (((tid >> 8) & 1) && s >= NPT / 2) __builtin_amdgcn_s_setprio(1);
+#endif
             if (!(flags[s] & 8)) continue;
             const int lt = t_lt(s);
             const double2 *xy = t_xy(s), *pim = xy + cap;
@@ -858,6 +896,9 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             acc[2] += r[s].x * fx + r[s].y * fy;
             acc[3] += fx * fx + fy * fy;
         }
+#if MAG_PERSIST_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         MAG_STAMP(2) // ring walks of this wave's nodes, q published
         persist_block_sum<THREADS>(acc, s_red);
         par ^= 1;
