@@ -100,14 +100,16 @@ __device__ inline void fan_force(const V2 db, const V2 ub, const V2 dc, const V2
 // one block the gathers of all NU entries issue up front and the NU - 1 chains interleave.
 // A second block, entries NU .. NU2 - 1, is walked the same way when the rows have at least NU2 entries (ROCm 7.2's
 // iterative-ilp scheduler, the fastest for this kernel, crashes on blocks of more than four triangles).
-template <int NW, int NU = 1, int NU2 = NU>
+// IDMASK / toff: the on-chip kernel rewrites the entries in its registers to WORKGROUP-wide LDS slots (15 bits); entries of
+// longer rows still come from the table in memory, tile-local, and are moved by the tile's slot offset `toff`.
+template <int NW, int NU = 1, int NU2 = NU, uint32_t IDMASK = 0xfffu>
 __device__ inline void ring_walk_uniform(const uint32_t (&w)[NW], const uint32_t *more, int32_t stride, int32_t nent,
                                          const double2 *s_xy, const double2 *s_p, const double2 ca, const double2 pa,
-                                         double c0, double nu, double h, double &fx, double &fy)
+                                         double c0, double nu, double h, double &fx, double &fy, uint32_t toff = 0)
 {
     double2 pd, pu;
     auto step = [&](uint32_t e, bool seed) {
-        const uint32_t id = e & 0xfffu;
+        const uint32_t id = e & IDMASK;
         const double2 cxy = s_xy[id], cp = s_p[id];
         const double2 d = make_double2(cxy.x - ca.x, cxy.y - ca.y), u = make_double2(cp.x - pa.x, cp.y - pa.y);
         if (!seed) {
@@ -143,7 +145,8 @@ __device__ inline void ring_walk_uniform(const uint32_t (&w)[NW], const uint32_t
         if (k < nent) step(entry(k), false);
     for (int32_t k = 2 * NW; k < nent; ++k) {
         const uint32_t ww = more[(int64_t)(k >> 1) * stride];
-        step((k & 1) ? (ww >> 16) : (ww & 0xffffu), false);
+        const uint32_t e = (k & 1) ? (ww >> 16) : (ww & 0xffffu);
+        step(((e & 0xfffu) + toff) | (e & 0x8000u), false);
     }
 }
 
@@ -154,14 +157,14 @@ __device__ inline void ring_walk_uniform(const uint32_t (&w)[NW], const uint32_t
 // folded into the weight (0 for an entry that closes no triangle: its bracket is finite, 0 x finite adds nothing), so
 // the per-entry selects go as well.  NC weights per node (a closed fan of valence 6 has 6 triangles); triangles beyond
 // NC are evaluated as before.
-template <int NW, int NC>
+template <int NW, int NC, uint32_t IDMASK = 0xfffu>
 __device__ inline void ring_weights(const uint32_t (&w)[NW], int32_t nent, const double2 *s_xy, const double2 ca, double c0,
                                     double (&wgt)[NC])
 {
     double2 pd;
     auto entry = [&](int k) { return (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu); };
     {
-        const double2 cxy = s_xy[entry(0) & 0xfffu];
+        const double2 cxy = s_xy[entry(0) & IDMASK];
         pd = make_double2(cxy.x - ca.x, cxy.y - ca.y);
     }
 #pragma unroll
@@ -169,7 +172,7 @@ __device__ inline void ring_weights(const uint32_t (&w)[NW], int32_t nent, const
         wgt[k - 1] = 0.0;
         if (k < nent && k < 2 * NW) {
             const uint32_t e = entry(k);
-            const double2 cxy = s_xy[e & 0xfffu];
+            const double2 cxy = s_xy[e & IDMASK];
             const double2 d = make_double2(cxy.x - ca.x, cxy.y - ca.y);
             const double twoA = pd.x * d.y - d.x * pd.y;
             if (!(e & 0x8000u)) wgt[k - 1] = c0 * fast_rcp(twoA);
@@ -190,15 +193,16 @@ __device__ inline void fan_force_w(const V2 db, const V2 ub, const V2 dc, const 
     fy += wt * (ga * sy + ba * tq);
 }
 
-template <int NW, int NC>
+template <int NW, int NC, uint32_t IDMASK = 0xfffu>
 __device__ inline void ring_walk_cached(const uint32_t (&w)[NW], const uint32_t *more, int32_t stride, int32_t nent,
                                         const double2 *s_xy, const double2 *s_p, const double2 ca, const double2 pa,
-                                        double c0, double nu, double h, const double (&wgt)[NC], double &fx, double &fy)
+                                        double c0, double nu, double h, const double (&wgt)[NC], double &fx, double &fy,
+                                        uint32_t toff = 0)
 {
     double2 pd, pu;
     auto entry = [&](int k) { return (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu); };
     auto gather = [&](uint32_t e, double2 &d, double2 &u) {
-        const uint32_t id = e & 0xfffu;
+        const uint32_t id = e & IDMASK;
         const double2 cxy = s_xy[id], cp = s_p[id];
         d = make_double2(cxy.x - ca.x, cxy.y - ca.y);
         u = make_double2(cp.x - pa.x, cp.y - pa.y);
@@ -224,7 +228,8 @@ __device__ inline void ring_walk_cached(const uint32_t (&w)[NW], const uint32_t 
         }
     for (int32_t k = 2 * NW; k < nent; ++k) {
         const uint32_t ww = more[(int64_t)(k >> 1) * stride];
-        const uint32_t e = (k & 1) ? (ww >> 16) : (ww & 0xffffu);
+        const uint32_t e0 = (k & 1) ? (ww >> 16) : (ww & 0xffffu);
+        const uint32_t e = ((e0 & 0xfffu) + toff) | (e0 & 0x8000u);
         double2 d, u;
         gather(e, d, u);
         double dfx = 0.0, dfy = 0.0;

@@ -572,8 +572,10 @@ __device__ inline void persist_block_sum(double (&acc)[4], double *s_red)
 
 constexpr int kPersistRegs = 5; // ring words in registers per node: 10 entries, a closed fan of valence <= 9
 #ifndef MAG_PERSIST_BLOCK
-#define MAG_PERSIST_BLOCK 5 // measured on one box (us per iteration, 1M triangles): no block 11.06-11.10, 5: 11.02, 4+3: 11.19-11.21,
-#endif                      // 5+2: 11.14; one block of 7 only compiles without iterative-ilp: 11.41-11.71 (profiles/r03_persist_ab.txt)
+#define MAG_PERSIST_BLOCK 1 // (uncached walks only, i.e. the multi-GPU instantiation) measured in round 3, us per iteration at 1M
+#endif                      // triangles: no block 11.06-11.10, 5: 11.02, 4+3: 11.19-11.21, 5+2: 11.14; one block of 7 only compiles
+                            // without iterative-ilp: 11.41-11.71 (profiles/r03_persist_ab.txt).  Back to 1: with the
+                            // tile-relative slots below ROCm 7.2's iterative-ilp scheduler crashes on any block.
 #ifndef MAG_PERSIST_BLOCK2
 #define MAG_PERSIST_BLOCK2 MAG_PERSIST_BLOCK
 #endif
@@ -582,6 +584,10 @@ constexpr int kPersistBlock = MAG_PERSIST_BLOCK, kPersistBlock2 = MAG_PERSIST_BL
 #ifndef MAG_PERSIST_WEIGHTS
 #define MAG_PERSIST_WEIGHTS 6
 #endif
+#ifndef MAG_PERSIST_SIBLINGS
+#define MAG_PERSIST_SIBLINGS 1
+#endif
+constexpr bool kPersistSiblings = MAG_PERSIST_SIBLINGS != 0; // sibling tiles of a workgroup read each other's LDS slots
 #ifndef MAG_PERSIST_PRIO
 #define MAG_PERSIST_PRIO 3 // waves 4-7 (the arbitration losers of their SIMDs) take priority for their last two node slots: 9.55 -> 9.21 us
 #endif
@@ -680,6 +686,33 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
 #pragma unroll
         for (int k = 0; k < kPersistRegs; ++k)
             if (k < deg[s]) w[s][k] = P.ell16[ell_off[s] + (int64_t)k * B];
+        // Ring entries become slots RELATIVE TO THE WORKGROUP'S TILES: entry = 3 * tile_words + (owner tile - this tile) *
+        // tile_words + position, read through this tile's base moved down by 3 * tile_words (15 bits: up to seven tile images).
+        // A reference to a node that a SIBLING tile of this workgroup owns then points straight at the owner's slots (its
+        // coordinates, its p), and the reader keeps no halo copy of it: no q to fetch for it, no r / p to advance -- about half
+        // of a workgroup's halo entries when its tiles are consecutive in the Hilbert order.  Only for tiles whose rows all sit
+        // in the registers (longer rows read tile-local entries from memory every iteration and keep their halo copies).
+        // (One base per tile rather than one for the workgroup: with a common base ROCm 7.2's allocator spills 30 registers
+        // into the walks.)
+        {
+            const int32_t t_first = (MG ? P.t0 : 0) + blockIdx.x * P.tiles_per_wg, t_end = MG ? P.t1 : P.T;
+            // (single-GPU instantiation only: a workgroup of several tiles next to other ranks cannot be rehearsed on one GPU)
+            const bool short_rows = kPersistSiblings && !MG && tm.ent <= 2 * kPersistRegs;
+            auto remap = [&](uint32_t e) -> uint32_t {
+                if (e == 0xffffu) return e;
+                const uint32_t lid = e & 0xfffu;
+                uint32_t slot = (uint32_t)(3 * tile_words) + lid;
+                if (short_rows && lid >= (uint32_t)B) {
+                    const int32_t g = P.halo_g[tm.hoff + (int32_t)(lid - B)];
+                    const int32_t ot = g / B, ol = ot - t_first;
+                    if (ol >= 0 && ol < P.tiles_per_wg && ot < t_end) slot = (uint32_t)((3 + ol - l) * tile_words + (g - ot * B));
+                }
+                return slot | (e & 0x8000u);
+            };
+#pragma unroll
+            for (int k = 0; k < kPersistRegs; ++k)
+                if (k < deg[s]) w[s][k] = remap(w[s][k] & 0xffffu) | (remap(w[s][k] >> 16) << 16);
+        }
         if ((flags[s] & 20) == 20) put_granules(P.qg + 4 * nd, tag0, make_double2(0.0, 0.0)); // q_{-1} = 0, parity 0
         if (MG && (flags[s] & 16)) {
             oslot[s] = P.own_qslot[nd];
@@ -699,6 +732,13 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
                 if (rem < tm.nh) {
                     double2 *xy = smem + (size_t)l * tile_words;
                     hg[e] = P.halo_g[tm.hoff + rem];
+                    {
+                        const int32_t ot = hg[e] / B, ol = ot - t_first;
+                        if (kPersistSiblings && !MG && tm.ent <= 2 * kPersistRegs && ol >= 0 && ol < P.tiles_per_wg && ot < t_end) {
+                            hg[e] = -1; // a sibling tile owns it: this tile's walks read the owner's slots
+                            break;
+                        }
+                    }
                     hloc[e] = l * tile_words + rem;
                     xy[B + rem] = P.halo_xy[tm.hoff + rem];
                     const double2 hb = P.bP[hg[e]];
@@ -744,7 +784,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             if (!(flags[s] & 8)) continue;
             const double2 *xy = t_xy(s);
             const int32_t nent = __builtin_amdgcn_readfirstlane(ent[s]);
-            if (nent > 0) ring_weights<kPersistRegs, NCW>(w[s], nent, xy, xy[t_lt(s)], c0, wgt[s]);
+            if (nent > 0) ring_weights<kPersistRegs, NCW, 0x7fffu>(w[s], nent, xy - 3 * tile_words, xy[t_lt(s)], c0, wgt[s]);
         }
     }
     double target = P.tol, bb = 0.0;
@@ -876,13 +916,15 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             double fx = 0.0, fy = 0.0;
             {
                 const int32_t nent = __builtin_amdgcn_readfirstlane(ent[s]); // one tile per wave: a scalar
-                if (nent > 0) {
+                if (nent > 0) { // entries are biased slots relative to this tile (see the remap at the top)
+                    const uint32_t toff = (uint32_t)(3 * tile_words);
                     if (CACHED)
-                        ring_walk_cached<kPersistRegs, NCW>(w[s], P.ell16 + ell_off[s], B, nent, xy, pim, ca, pa, c0, nu,
-                                                            h, wgt[s], fx, fy);
+                        ring_walk_cached<kPersistRegs, NCW, 0x7fffu>(w[s], P.ell16 + ell_off[s], B, nent, xy - 3 * tile_words, pim - 3 * tile_words,
+                                                                     ca, pa, c0, nu, h, wgt[s], fx, fy, toff);
                     else
-                        ring_walk_uniform<kPersistRegs, kPersistBlock, kPersistBlock2>(w[s], P.ell16 + ell_off[s], B, nent,
-                                                                                      xy, pim, ca, pa, c0, nu, h, fx, fy);
+                        ring_walk_uniform<kPersistRegs, kPersistBlock, kPersistBlock2, 0x7fffu>(
+                            w[s], P.ell16 + ell_off[s], B, nent, xy - 3 * tile_words, pim - 3 * tile_words, ca, pa, c0, nu, h, fx, fy,
+                            toff);
                 }
             }
             if ((flags[s] & 1) || !(flags[s] & 16)) fx = 0.0;
