@@ -120,10 +120,12 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
     // ~0.85 us in all: the other workgroups' records are still on their way, and a sweep that comes too early costs a
     // full round trip.  Two fixed s_sleep instructions, re-tuned in round 2 on one box (us per iteration at 1M triangles):
     // 10+10 10.89, 12+12 10.85, 14+14 10.79, 16+8 10.85, 16+16 10.62, 18+14 10.58, 20+20 10.67, 24+24 10.86; one
-    // s_sleep(32) 10.74, one s_sleep(40) 10.79; the same 40 units as a run-time loop of ten s_sleep(4) 10.87.
+    // s_sleep(32) 10.74, one s_sleep(40) 10.79; the same 40 units as a run-time loop of ten s_sleep(4) 10.87.  Round 3, with the
+    // shorter walks and half the halo fetched (profiles/r03_persist_ab.txt): 10+6 8.91, 12+10 8.70, 14+8 8.70, 14+10 8.70,
+    // 14+12 8.73, 16+10 8.72, 18+14 8.80, 22+16 8.95, 26+20 9.19, one s_sleep(24) 8.72.
 #ifndef MAG_PERSIST_SLEEP1
-#define MAG_PERSIST_SLEEP1 18
-#define MAG_PERSIST_SLEEP2 14
+#define MAG_PERSIST_SLEEP1 14
+#define MAG_PERSIST_SLEEP2 10
 #endif
     __builtin_amdgcn_s_sleep(MAG_PERSIST_SLEEP1);
     if (MAG_PERSIST_SLEEP2 > 0) __builtin_amdgcn_s_sleep(MAG_PERSIST_SLEEP2);
