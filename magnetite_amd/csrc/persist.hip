@@ -211,19 +211,14 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
         return false;
     }
     // every workgroup sums the same values in the same order (four records per lane, then the lanes): same bits
-    // everywhere
-    if (tid < 64) {
-        double S[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int m = tid; m < grid; m += 64) {
-            const double2 a = s_rec[2 * m], b = s_rec[2 * m + 1];
-            S[0] += a.x;
-            S[1] += a.y;
-            S[2] += b.x;
-            S[3] += b.y;
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) S[c] = wave_sum_dpp(S[c]);
-        if (tid < 4) s_S[tid] = tid == 0 ? S[0] : (tid == 1 ? S[1] : (tid == 2 ? S[2] : S[3]));
+    // everywhere.  Waves 0-3 take one of the four sums each (they sit on four different SIMDs): a quarter of the chain.
+    if (tid < 256) {
+        const int c = tid >> 6, lane = tid & 63;
+        const double *rec = (const double *)s_rec; // record m: doubles 4 m .. 4 m + 3
+        double S = 0.0;
+        for (int m = lane; m < grid; m += 64) S += rec[4 * m + c];
+        S = wave_sum_dpp(S);
+        if (lane == 0) s_S[c] = S;
     }
     __syncthreads();
     return true;
@@ -674,7 +669,11 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             const double2 b = P.bP[nd];
             r[s] = make_double2(-b.x, -b.y);
             xy[lt] = P.xyP[nd];
-            flags[s] |= 16u | (uint32_t)(P.maskP[nd] & 7);
+            const uint32_t mk = P.maskP[nd];
+            flags[s] |= 16u | (mk & 7u);
+            // bit 3 of the mask (k_mark_external): read through memory by a tile of ANOTHER workgroup, or by a sibling tile
+            // that keeps its halo copies; a node only its siblings read through their LDS slots publishes nothing
+            if (kPersistSiblings && !MG && !(mk & 8u)) flags[s] &= ~4u;
             acc[0] += b.x * b.x + b.y * b.y;
         } else {
             xy[lt] = make_double2(0.0, 0.0);
@@ -1204,6 +1203,28 @@ bool persist_stamps_built()
 #else
     return false;
 #endif
+}
+
+// bit 3 of the node mask, for the on-chip kernel with `k` tiles per workgroup: some tile reads this node THROUGH MEMORY -- a
+// tile of another workgroup, or a sibling tile whose rows do not all fit the registers (it keeps its halo copies).  One
+// block per reading tile.
+__global__ void __launch_bounds__(256) k_mark_external(const int32_t *halo_g, const TileMeta *meta, int32_t B, int32_t k,
+                                                       int32_t max_reg_entries, uint8_t *maskP)
+{
+    const int32_t t = blockIdx.x;
+    const TileMeta tm = meta[t];
+    for (int32_t h = threadIdx.x; h < tm.nh; h += 256) {
+        const int64_t g = halo_g[tm.hoff + h];
+        const int32_t ot = (int32_t)(g / B);
+        if (ot / k != t / k || tm.ent > max_reg_entries)
+            atomicOr((unsigned int *)(maskP + (g & ~(int64_t)3)), 8u << (8 * (g & 3)));
+    }
+}
+
+void mark_external(const int32_t *halo_g, const TileMeta *meta, int32_t T, int32_t B, int32_t k, uint8_t *maskP,
+                   hipStream_t s)
+{
+    if (T > 0) k_mark_external<<<T, 256, 0, s>>>(halo_g, meta, B, k, 2 * kPersistRegs, maskP);
 }
 
 // bit 2 of the node mask: some tile reads this node through its halo list, so its owner must publish q
