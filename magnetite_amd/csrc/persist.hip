@@ -122,10 +122,11 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
     // 10+10 10.89, 12+12 10.85, 14+14 10.79, 16+8 10.85, 16+16 10.62, 18+14 10.58, 20+20 10.67, 24+24 10.86; one
     // s_sleep(32) 10.74, one s_sleep(40) 10.79; the same 40 units as a run-time loop of ten s_sleep(4) 10.87.  Round 3, with the
     // shorter walks and half the halo fetched (profiles/r03_persist_ab.txt): 10+6 8.91, 12+10 8.70, 14+8 8.70, 14+10 8.70,
-    // 14+12 8.73, 16+10 8.72, 18+14 8.80, 22+16 8.95, 26+20 9.19, one s_sleep(24) 8.72.
+    // 14+12 8.73, 16+10 8.72, 18+14 8.80, 22+16 8.95, 26+20 9.19, one s_sleep(24) 8.72.  With x += alpha p moved into this
+    // wait (it takes about half of it): 2 8.34, 4+2 8.20, 6+4 8.23 (4.44 at 100k, where 4+2 gives 4.60), 8+6 8.30, 10+8 8.36.
 #ifndef MAG_PERSIST_SLEEP1
-#define MAG_PERSIST_SLEEP1 14
-#define MAG_PERSIST_SLEEP2 10
+#define MAG_PERSIST_SLEEP1 6
+#define MAG_PERSIST_SLEEP2 4
 #endif
     __builtin_amdgcn_s_sleep(MAG_PERSIST_SLEEP1);
     if (MAG_PERSIST_SLEEP2 > 0) __builtin_amdgcn_s_sleep(MAG_PERSIST_SLEEP2);
@@ -585,6 +586,10 @@ constexpr int kPersistBlock = MAG_PERSIST_BLOCK, kPersistBlock2 = MAG_PERSIST_BL
 #define MAG_PERSIST_SIBLINGS 1
 #endif
 constexpr bool kPersistSiblings = MAG_PERSIST_SIBLINGS != 0; // sibling tiles of a workgroup read each other's LDS slots
+#ifndef MAG_PERSIST_DEFER_X
+#define MAG_PERSIST_DEFER_X 1
+#endif
+constexpr bool kPersistDeferX = MAG_PERSIST_DEFER_X != 0; // x += alpha p in the exchange's first wait (see the loop)
 #ifndef MAG_PERSIST_PRIO
 #define MAG_PERSIST_PRIO 3 // waves 4-7 (the arbitration losers of their SIMDs) take priority for their last two node slots: 9.55 -> 9.21 us
 #endif
@@ -744,7 +749,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
                     xy[B + rem] = P.halo_xy[tm.hoff + rem];
                     const double2 hb = P.bP[hg[e]];
                     xy[2 * cap + rem] = make_double2(-hb.x, -hb.y);      // halo r
-                    xy[2 * cap + maxh + rem] = make_double2(0.0, 0.0); // halo p
+                    xy[cap + B + rem] = make_double2(0.0, 0.0);        // halo p: its slot in the p image
                     if (MG) { // a node another rank owns: its q comes through the window (slot s encoded as -2 - s)
                         const int32_t hs = P.halo_qslot[tm.hoff + rem];
                         if (hs >= 0) hg[e] = -2 - hs;
@@ -836,6 +841,11 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         const double alpha = rr / S1;
         const double beta = (rr + 2.0 * alpha * S2 + alpha * alpha * S3) / rr;
 
+        // x += alpha p is the one update nothing in the iteration waits for.  It is done in the idle time before the first
+        // sweep of the exchange, from what is on the chip by then: alpha p_{j-1} = (alpha / beta) (p_j + r_j) (p_j = -r_j +
+        // beta p_{j-1}); x feeds back into nothing, so the iterates and the iteration count are untouched and x itself moves by
+        // a few ulps per step.  beta = 0 (an exactly zero residual) cannot be divided by: then, and only then, here.
+        const bool xnow = !(beta != 0.0) || !(fabs(beta) <= 1.79769313486231570e308);
         // ---- vector updates: r in registers, p and x in LDS, halo copies in LDS (their q from the publishers)
 #if MAG_PERSIST_PRIO == 11
         if ((tid >> 8) & 1) __builtin_amdgcn_s_setprio(1);
@@ -848,10 +858,13 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             const int lt = t_lt(s);
             double2 *xy = t_xy(s), *pim = xy + cap, *hr = pim + cap, *hp = hr + maxh, *xs = hp + maxh;
             const double2 po = pim[lt];
-            double2 xo = xs[lt], pn;
-            xo.x += alpha * po.x;
-            xo.y += alpha * po.y;
-            xs[lt] = xo;
+            double2 pn;
+            if (!kPersistDeferX || xnow) { // x += alpha p here, on the critical path, only when it cannot be rebuilt later
+                double2 xo = xs[lt];
+                xo.x += alpha * po.x;
+                xo.y += alpha * po.y;
+                xs[lt] = xo;
+            }
             r[s].x += alpha * q[s].x;
             r[s].y += alpha * q[s].y;
             pn.x = -r[s].x + beta * po.x;
@@ -862,13 +875,12 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         for (int e = 0; e < NH; ++e)
             if (hg[e] != -1) {
                 double2 *hbase = smem + hloc[e]; // = tile base + position: coordinates at [B], p image at [cap + B], ...
-                double2 hrv = hbase[2 * cap], hpv = hbase[2 * cap + maxh];
+                double2 hrv = hbase[2 * cap], hpv = hbase[cap + B]; // the halo node's p lives in the p image itself
                 hrv.x += alpha * hq[e].x;
                 hrv.y += alpha * hq[e].y;
                 hpv.x = -hrv.x + beta * hpv.x;
                 hpv.y = -hrv.y + beta * hpv.y;
                 hbase[2 * cap] = hrv;
-                hbase[2 * cap + maxh] = hpv;
                 hbase[cap + B] = hpv;
             }
 #if MAG_PERSIST_PRIO == 11 || MAG_PERSIST_PRIO == 12
@@ -950,6 +962,20 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         if (tid < 2)
             put_granules(P.recg + 4 * (2 * ((int64_t)par * cgrid + blockIdx.x) + tid), epoch,
                          tid == 0 ? make_double2(acc[0], acc[1]) : make_double2(acc[2], acc[3]));
+        if (kPersistDeferX && !xnow) { // the deferred x += alpha p_{j-1}, in the shadow of the exchange's first wait
+            const double ab = alpha / beta;
+#pragma unroll
+            for (int s = 0; s < NPT; ++s) {
+                if (!(flags[s] & 8)) continue;
+                const int lt = t_lt(s);
+                double2 *xy = t_xy(s), *pim = xy + cap, *xs = pim + cap + 2 * maxh;
+                const double2 pj = pim[lt];
+                double2 xo = xs[lt];
+                xo.x += ab * (pj.x + r[s].x);
+                xo.y += ab * (pj.y + r[s].y);
+                xs[lt] = xo;
+            }
+        }
         MAG_STAMP(3) // workgroup sums (wave trees, barrier, eight waves in order) + record published
 #ifdef MAG_PERSIST_STAMPS
         unsigned long long xs_[3] = {0, 0, 0};
