@@ -613,6 +613,9 @@ constexpr int persist_npt(int threads) { return threads == 768 ? 3 : 4; } // nod
 #else
 #define MAG_STAMP(k)
 #endif
+#ifndef MAG_PERSIST_STAMP_TID
+#define MAG_PERSIST_STAMP_TID 0 // the lane that stamps (0: wave 0, the older wave of its SIMD; 256: wave 4, its partner)
+#endif
 [[maybe_unused]] constexpr int kStampFrom = 200, kStampTo = 1200;
 constexpr int kStampPhases = 8;
 
@@ -810,7 +813,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
 #endif
     for (;;) {
 #ifdef MAG_PERSIST_STAMPS
-        const bool stamping = tid == 0 && j >= kStampFrom && j < kStampTo;
+        const bool stamping = tid == MAG_PERSIST_STAMP_TID && j >= kStampFrom && j < kStampTo;
         if (stamping) {
             stamp_last = __builtin_amdgcn_s_memrealtime();
             ++stamp_iters;
@@ -847,11 +850,6 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         // a few ulps per step.  beta = 0 (an exactly zero residual) cannot be divided by: then, and only then, here.
         const bool xnow = !(beta != 0.0) || !(fabs(beta) <= 1.79769313486231570e308);
         // ---- vector updates: r in registers, p and x in LDS, halo copies in LDS (their q from the publishers)
-#if MAG_PERSIST_PRIO == 11
-        if ((tid >> 8) & 1) __builtin_amdgcn_s_setprio(1);
-#elif MAG_PERSIST_PRIO == 12
-        if (!((tid >> 8) & 1)) __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int s = 0; s < NPT; ++s) {
             if (!(flags[s] & 8)) continue;
@@ -883,9 +881,6 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
                 hbase[2 * cap] = hrv;
                 hbase[cap + B] = hpv;
             }
-#if MAG_PERSIST_PRIO == 11 || MAG_PERSIST_PRIO == 12
-        __builtin_amdgcn_s_setprio(0);
-#endif
         MAG_STAMP(0) // scalars + vector updates issued
         __syncthreads();
         MAG_STAMP(1) // ... landed in LDS for everybody (workgroup barrier)
@@ -895,31 +890,13 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         for (int c = 0; c < 4; ++c) acc[c] = 0.0;
 #pragma unroll
         for (int s = 0; s < NPT; ++s) {
-#if MAG_PERSIST_PRIO == 1
-            // the two waves of a SIMD take turns at the higher priority, one node slot each: both finish their walks
-            // together instead of the older one 2 us ahead of a partner that then runs alone
-            if ((((tid >> 8) & 1) ^ (s & 1)) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#elif MAG_PERSIST_PRIO == 2
-            if ((((tid >> 8) & 1) ^ ((s >> 1) & 1)) != 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#elif MAG_PERSIST_PRIO == 3
-            // the younger half (waves 4-7) is the arbitration loser: priority for its LAST two node slots only
-            if (((tid >> 8) & 1) && s >= NPT / 2) __builtin_amdgcn_s_setprio(1);
-#elif MAG_PERSIST_PRIO == 4
-            if (((tid >> 8) & 1) && s >= 1) __builtin_amdgcn_s_setprio(1);
-#elif MAG_PERSIST_PRIO == 5
-            if (((tid >> 8) & 1) && s >= NPT - 1) __builtin_amdgcn_s_setprio(1);
-#elif MAG_PERSIST_PRIO == 6
-            if ((tid >> 8) & 1) __builtin_amdgcn_s_setprio(1);
-#elif MAG_PERSIST_PRIO == 7
-            if ((tid >> 8) & 1) { if (s >= NPT / 2) __builtin_amdgcn_s_setprio(1); }
-            else { if (s < NPT / 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-#elif MAG_PERSIST_PRIO == 8
-            if (((tid >> 8) & 1) && s >= NPT / 2) __builtin_amdgcn_s_setprio(2);
-#elif MAG_PERSIST_PRIO == 9
-            if ((tid >> 8) & 1) { if (s < NPT / 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-#elif MAG_PERSIST_PRIO == 10
-            if ((tid >> 8) & 1) { if (s == 1 || s == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-#elif MAG_PERSIST_PRIO == 11 || MAG_PERSIST_PRIO == 12
+#if MAG_PERSIST_PRIO == 3
+            // The two waves of a SIMD run the same program, and at equal priority the older one (waves 0-3) wins every
+            // arbitration: the stamps showed it through its walks 2 us before its partner, which then ran alone, at
+            // single-wave efficiency.  Waves 4-7 take priority 1 for their LAST TWO node slots (back to 0 before the sums):
+            // the partners finish within 0.8 us of each other.  Twelve other schedules (static priority, alternating per
+            // slot or pair, one or three slots, three levels, priority during the vector updates) were measured and are in
+            // profiles/r03_persist_ab.txt (q0-q16): none better.
             if (((tid >> 8) & 1) && s >= NPT / 2) __builtin_amdgcn_s_setprio(1);
 #endif
             if (!(flags[s] & 8)) continue;
@@ -995,7 +972,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
 #endif
     }
 #ifdef MAG_PERSIST_STAMPS
-    if (tid == 0 && P.stamps) {
+    if (tid == MAG_PERSIST_STAMP_TID && P.stamps) {
         unsigned long long *o = P.stamps + (size_t)blockIdx.x * (kStampPhases + 1);
         for (int k = 0; k < kStampPhases; ++k) o[k] = stamp_sum[k];
         o[kStampPhases] = stamp_iters;

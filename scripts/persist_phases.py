@@ -35,7 +35,7 @@ print(json.dumps({k: st[k] for k in ("iterations", "ms_cg", "cg_kernel", "num_ti
 def run(workload, threads, stamps_file):
     env = dict(os.environ, MAG_TUNE_PERSIST_THREADS=str(threads))
     if stamps_file:
-        env["MAG_LIB_PATH"] = os.path.join(ROOT, "magnetite_amd", "libmagnetite_hip_stamps.so")
+        env["MAG_LIB_PATH"] = os.environ.get("MAG_STAMPS_LIB") or os.path.join(ROOT, "magnetite_amd", "libmagnetite_hip_stamps.so")
         env["MAG_TUNE_PERSIST_STAMPS"] = stamps_file
     r = subprocess.run([sys.executable, "-c", WORKER, workload], env=env, capture_output=True, text=True, timeout=600)
     if r.returncode != 0:
