@@ -627,9 +627,9 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
     extern __shared__ __attribute__((aligned(16))) double2 smem[];
     const int tid = threadIdx.x;
     const int cap = P.cap, maxh = P.maxh;
-    // LDS per local tile l: coordinates[cap], p image[cap] (owned part = the CG vector p itself), halo r[maxh],
-    // halo p[maxh], x[B].  Registers per node: r, q, the ring words.
-    const int tile_words = 2 * cap + 2 * maxh + B;
+    // LDS per local tile l: coordinates[cap], p image[cap] (owned part = the CG vector p itself; its halo part holds the halo
+    // nodes' p), halo r[maxh], x[B].  Registers per node: r, q, the ring words, the triangle weights.
+    const int tile_words = 2 * cap + maxh + B;
     double2 *s_rec = smem + (size_t)(NPT * THREADS / B) * tile_words; // 2 * grid pieces of the partial records
     double *s_red = (double *)(s_rec + 2 * 256);
     double *s_S = s_red + 4 * (kPersistThreads / 64);
@@ -658,7 +658,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
     for (int s = 0; s < NPT; ++s) {
         const int l = t_loc(s), lt = t_lt(s);
         const int32_t t = (MG ? P.t0 : 0) + blockIdx.x * P.tiles_per_wg + l;
-        double2 *xy = t_xy(s), *pim = xy + cap, *hr = pim + cap, *hp = hr + maxh, *xs = hp + maxh;
+        double2 *xy = t_xy(s), *pim = xy + cap, *hr = pim + cap, *xs = hr + maxh;
         node[s] = 0;
         oslot[s] = -1;
         deg[s] = 0;
@@ -854,7 +854,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         for (int s = 0; s < NPT; ++s) {
             if (!(flags[s] & 8)) continue;
             const int lt = t_lt(s);
-            double2 *xy = t_xy(s), *pim = xy + cap, *hr = pim + cap, *hp = hr + maxh, *xs = hp + maxh;
+            double2 *xy = t_xy(s), *pim = xy + cap, *hr = pim + cap, *xs = hr + maxh;
             const double2 po = pim[lt];
             double2 pn;
             if (!kPersistDeferX || xnow) { // x += alpha p here, on the critical path, only when it cannot be rebuilt later
@@ -945,7 +945,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             for (int s = 0; s < NPT; ++s) {
                 if (!(flags[s] & 8)) continue;
                 const int lt = t_lt(s);
-                double2 *xy = t_xy(s), *pim = xy + cap, *xs = pim + cap + 2 * maxh;
+                double2 *xy = t_xy(s), *pim = xy + cap, *xs = pim + cap + maxh;
                 const double2 pj = pim[lt];
                 double2 xo = xs[lt];
                 xo.x += ab * (pj.x + r[s].x);
@@ -981,7 +981,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
     // x of iterate j-1 is in LDS; the verdict is the same in every workgroup
 #pragma unroll
     for (int s = 0; s < NPT; ++s)
-        if ((flags[s] & 24) == 24) P.x[node[s]] = (t_xy(s) + 2 * cap + 2 * maxh)[t_lt(s)];
+        if ((flags[s] & 24) == 24) P.x[node[s]] = (t_xy(s) + 2 * cap + maxh)[t_lt(s)];
     if (blockIdx.x == 0 && tid == 0) {
         FusedState *st = P.st;
         st->bb = bb;
@@ -1171,7 +1171,7 @@ int persist_tiles_per_wg(int32_t B, int threads)
 size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh, int threads)
 {
     const size_t tiles = (size_t)persist_tiles_per_wg(B, threads);
-    return tiles * (2 * (size_t)cap + 2 * (size_t)maxh + (size_t)B) * 16 + 2 * 256 * 16 +
+    return tiles * (2 * (size_t)cap + (size_t)maxh + (size_t)B) * 16 + 2 * 256 * 16 +
            (4 * ((size_t)threads / 64) + 4 + 4 * 32) * 8 + 16;
 }
 
