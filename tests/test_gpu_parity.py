@@ -936,6 +936,50 @@ def test_on_chip_cg_with_rings_longer_than_its_registers(built):
         assert rel(out["u"], ref["u"]) <= TOL_U and abs(out["iterations"] - ref["iterations"]) <= 3
 
 
+def _plate_with_a_hub(nx):
+    """plate(nx) with ONE interior node of valence 12: each of its six triangles (v, a, b) is split at the midpoint of
+    the ring edge a-b (the midpoints hang on the outer side: non-conforming, which neither solver minds)."""
+    m = meshgen.plate(nx)
+    v = (nx // 3) * (nx + 1) + nx // 3
+    conn, xy = m.conn.tolist(), m.xy.tolist()
+    out = []
+    for tri in conn:
+        if v not in tri:
+            out.append(tri)
+            continue
+        k = tri.index(v)
+        a, b = tri[(k + 1) % 3], tri[(k + 2) % 3]
+        xy.append([(xy[a][0] + xy[b][0]) / 2, (xy[a][1] + xy[b][1]) / 2])
+        mid = len(xy) - 1
+        out += [[v, a, mid], [v, mid, b]]
+    return meshgen.Mesh(np.array(xy), np.array(out, dtype=np.int32), f"hub_plate_{nx}")
+
+
+@pytest.mark.parametrize("case", ["perturbed_hole", "hub"])
+def test_on_chip_sibling_tiles_on_irregular_meshes(built, case):
+    """Two 512-node tiles per workgroup (more than 256 tiles): the tiles of a workgroup read each other's LDS slots instead of
+    keeping halo copies of each other's nodes, and nodes only siblings read publish nothing.  Shuffled caller numbering,
+    perturbed coordinates and a stair-step hole; and a mesh with a valence-12 node, whose tile has rows longer than the
+    registers hold: that tile keeps its halo copies (its siblings must still publish for it) while the others do not."""
+    if case == "hub":
+        mesh = meshgen.shuffle(meshgen.perturb(_plate_with_a_hub(372), 0.15, 3), 11)
+    else:
+        mesh = meshgen.shuffle(meshgen.perturb(meshgen.plate_with_holes(385), 0.2, 5), 9)
+    p = meshgen.config_fixed_left_pull_right(mesh)
+    assert p.mesh.num_nodes > 256 * 512  # two tiles per workgroup
+    ref = oracle_run(p, stop_mode=oracle.STOP_REL, tol=1e-9)
+    with Context(device=0, stop_mode=MAG_STOP_REL, tol=1e-9) as c:
+        out = c.solve(p)
+        st = c.stats()
+        again = c.solve(p)
+    assert st["cg_kernel"] == 2 and st["num_tiles"] > 256 and out["converged"] == 1
+    assert abs(out["iterations"] - ref["iterations"]) <= max(3, ref["iterations"] // 200)
+    assert rel(out["u"], ref["u"]) <= TOL_U and np.array_equal(out["u"], again["u"])
+    with Context(device=0, stop_mode=MAG_STOP_REL, tol=1e-9, cg_variant=1) as c:
+        streamed = c.solve(p)
+    assert rel(out["u"], streamed["u"]) <= 1e-9
+
+
 def test_one_context_alternates_between_streaming_and_on_chip_solves(built):
     """The same context solves a mesh the library streams (auto tile 256), one it keeps on chip (auto tile 512), and the
     first again: tile size, tables, graph and kernel choice all follow the problem, results equal fresh contexts'."""
