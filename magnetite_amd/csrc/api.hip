@@ -84,7 +84,7 @@ struct mag_ctx {
     int64_t ell_total = 0;
     DevBuf scratch, small; // rocPRIM temp; small = bbox partials, bbox, err flag
     DevBuf sK0, sK1, sV0, sV1;
-    DevBuf perm, iperm, xyP, maskP, deg, inc_off, inc, tile_deg, tile_rdeg, tile_cnt, tile_off, ell, ell_asm;
+    DevBuf perm, iperm, xyP, maskP, deg, inc_off, inc, tile_deg, tile_rdeg, tile_cnt, tile_off, ell, ell_asm, ell_pos;
     bool asm_ctile = false; // K is assembled from the CG tiles (k_assemble_fan), ell_asm holds its corner words
     // tile-local numbering for the LDS-halo operator
     bool use_lds = false;
@@ -426,10 +426,12 @@ int ensure_order(mag_ctx *ctx)
         ctx->asm_ctile = csr_wanted && !(how_asm && strcmp(how_asm, "ctile") != 0) && !getenv("MAG_TUNE_KE_BUFFER") &&
                          (B == 256 || B == 512) && ctx->cap <= 4096 && magk::assemble_ctiles_lds(B, ctx->cap) <= 64 * 1024;
         if (ctx->asm_ctile) HIPCHK(ctx->ell_asm.reserve(4 * (size_t)(h_total > 0 ? h_total : 1)));
+        if (ctx->asm_ctile) HIPCHK(ctx->ell_pos.reserve(2 * (size_t)(h_total > 0 ? h_total : 1)));
         magk::fill_ell16(ctx->inc_off.as<int32_t>(), ctx->inc.as<uint32_t>(), ctx->conn.as<int32_t>(),
                          ctx->iperm.as<int32_t>(), ctx->tile_deg.as<int32_t>(), ctx->tile_off.as<int64_t>(),
                          ctx->tile_hoff.as<int32_t>(), ctx->halo_g.as<int32_t>(), N, B, T, ctx->ell.as<uint32_t>(),
-                         ctx->asm_ctile ? ctx->ell_asm.as<uint32_t>() : nullptr, s);
+                         ctx->asm_ctile ? ctx->ell_asm.as<uint32_t>() : nullptr,
+                         ctx->asm_ctile ? ctx->ell_pos.as<uint16_t>() : nullptr, s);
         HIPCHK(ctx->tile_rdeg.reserve(2 * 4 * ((size_t)T + 1)));
         magk::ring16(ctx->tile_deg.as<int32_t>(), ctx->tile_off.as<int64_t>(), B, T, ctx->ell.as<uint32_t>(),
                      ctx->tile_rdeg.as<int32_t>(), s);
@@ -615,9 +617,10 @@ int gather_phase(mag_ctx *ctx)
                             ctx->kval.as<double>(), ctx->stream);
     } else if (ctx->asm_ctile && ctx->use_lds && !(how && !strcmp(how, "tiles")) &&
                magk::assemble_ctiles(ctx->bcol.as<int32_t>(), ctx->bptr.as<int32_t>(), ctx->perm.as<uint32_t>(),
-                                     ctx->xyP.as<double>(), ctx->halo_xy.as<double>(), ctx->halo_g.as<int32_t>(),
+                                     ctx->xyP.as<double>(), ctx->halo_xy.as<double>(),
                                      ctx->tile_hoff.as<int32_t>(), ctx->tile_deg.as<int32_t>(), ctx->tile_off.as<int64_t>(),
-                                     ctx->ell_asm.as<uint32_t>(), ctx->inc_off.as<int32_t>(), ctx->inc.as<uint32_t>(),
+                                     ctx->ell_asm.as<uint32_t>(), ctx->ell_pos.as<uint16_t>(),
+                                     ctx->inc_off.as<int32_t>(), ctx->inc.as<uint32_t>(),
                                      ctx->conn.as<int32_t>(), ctx->xy.as<double>(), ctx->N, ctx->B, ctx->T, ctx->cap,
                                      ctx->nu, ctx->youngs, ctx->thick, ctx->kval.as<double>(), ctx->stream)) {
         // assembled from the CG tiles (coordinates and caller ids staged in LDS)

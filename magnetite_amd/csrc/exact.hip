@@ -440,8 +440,9 @@ void assemble_tiles(const int32_t *bcol, const int32_t *bptr, const int32_t *inc
 // with r = RN(1 / 2A) (one true division) each quotient is x r corrected twice with exact FMA residuals (Markstein's
 // sequence, the one IA-64 and POWER divide with): RN(x / 2A), the reference's bits, in 5 instructions instead of a
 // ~13-instruction division each.  Valid while nothing under- or overflows and 2A's significand is not all ones:
-// guaranteed per tile by a range check of the staged coordinates (0 or 1e-150 < |c| < 1e100, so a non-zero difference is
-// >= 2e-166) and per element by 1e-100 < |2A| < 1e100; otherwise the true divisions run.
+// guaranteed per tile by a range check of the staged coordinates (0 or 1e-150 < |c| < 1e30, so a non-zero difference is
+// >= 2e-166) and per element by 1e-40 < |2A| < 1e60; otherwise the true divisions run.  Under the same bounds (and
+// |D| < 1e60, |thickness| < 1e30) the terms with a structural zero of B or D are left out (see asm_fan_blocks).
 // Rows the scheme does not cover -- more than 8 triangles or 8 blocks, an edge with three or more triangles, an element
 // that lists a node twice -- are finished by the whole workgroup with the k_assemble_rows arithmetic (label order, true
 // divisions), as in k_assemble_tiles.  Tiles whose image does not fit fall back to k_assemble_tiles altogether.
@@ -457,7 +458,7 @@ __device__ inline double div_shared(double x, double d, double r)
 __device__ inline bool coord_in_range(double c)
 {
     const double a = fabs(c);
-    return c == 0.0 || (a > 1e-150 && a < 1e100);
+    return c == 0.0 || (a > 1e-150 && a < 1e30);
 }
 
 // The three 2x2 blocks of row a from triangle (a, b, c), the three nodes distinct, in the rotated frame: dg = K_e[a][a],
@@ -477,7 +478,7 @@ __device__ inline void asm_fan_blocks(int a, const double2 va, const double2 vb,
     const double d = 2.0 * area;
     double ba, bb, bc, ga, gb, gc, z;
     const unsigned long long dbits = (unsigned long long)__double_as_longlong(d);
-    const bool quick = sane && fabs(d) > 1e-100 && fabs(d) < 1e100 &&
+    const bool quick = sane && fabs(d) > 1e-40 && fabs(d) < 1e60 &&
                        (dbits & 0x000fffffffffffffull) != 0x000fffffffffffffull;
     if (quick) {
         const double r = 1.0 / d; // correctly rounded: the one true division
@@ -487,16 +488,33 @@ __device__ inline void asm_fan_blocks(int a, const double2 va, const double2 vb,
         ga = div_shared(nga, d, r);
         gb = div_shared(ngb, d, r);
         gc = div_shared(ngc, d, r);
-        z = __builtin_copysign(0.0, d); // 0.0 / d for a finite non-zero d
-    } else {
-        ba = nba / d;
-        bb = nbb / d;
-        bc = nbc / d;
-        ga = nga / d;
-        gb = ngb / d;
-        gc = ngc / d;
-        z = 0.0 / d; // the structural zeros of B after the division
+        // `sane` bounds every factor (|coordinates| < 1e30, |D| < 1e60, |thickness| < 1e30) and here |2A| > 1e-40, so
+        // nothing below overflows: quotients < 2e70, B^T D < 2e130, the sums < 8e200, * area * thickness < 4e290.  Then
+        // every term the reference forms with a structural zero of B (0.0 / 2A) or of D (0.0 * E / (1 - nu^2)) is +-0, and
+        // x + (+-0) = x for x != 0: leaving those terms out can only change the SIGN of an intermediate zero, which no
+        // later operation turns into anything but a zero, and the scatter's `0.0 + c` makes that +0.0 either way.  What
+        // stays of rows 2a, 2a+1 of B^T D is (ba D00, ba D01, ga D22) and (ga D10, ga D11, ba D22), and of an entry the two
+        // products without a zero factor, in the reference's order.
+        const double Mx0 = ba * D[0], Mx1 = ba * D[1], Mx2 = ga * D[8];
+        const double My0 = ga * D[3], My1 = ga * D[4], My2 = ba * D[8];
+        auto block = [&](double bn, double gn, double (&c)[4]) {
+            c[0] = (Mx0 * bn + Mx2 * gn) * area * thick;
+            c[1] = (Mx1 * gn + Mx2 * bn) * area * thick;
+            c[2] = (My0 * bn + My2 * gn) * area * thick;
+            c[3] = (My1 * gn + My2 * bn) * area * thick;
+        };
+        block(ba, ga, dg);
+        block(bb, gb, kb);
+        block(bc, gc, kc);
+        return;
     }
+    ba = nba / d;
+    bb = nbb / d;
+    bc = nbc / d;
+    ga = nga / d;
+    gb = ngb / d;
+    gc = ngc / d;
+    z = 0.0 / d; // the structural zeros of B after the division
     // rows 2a, 2a+1 of B^T D, as ke_block forms them: columns (ba, z, ga) and (z, ga, ba) of B
     double Mx[3], My[3];
 #pragma unroll
@@ -535,26 +553,25 @@ constexpr int kFanLanes = 8;     // lanes (triangles, columns) per node
 template <int B>
 __global__ void __launch_bounds__(kFanThreads) k_assemble_fan(const int32_t *bcol, const int32_t *bptr, const uint32_t *perm,
                                                               const double2 *xyP, const double2 *halo_xy,
-                                                              const int32_t *halo_g, const int32_t *tile_hoff,
-                                                              const int32_t *tile_deg, const int64_t *tile_off,
-                                                              const uint32_t *ell_asm, const int32_t *inc_off,
+                                                              const int32_t *tile_hoff, const int32_t *tile_deg,
+                                                              const int64_t *tile_off, const uint32_t *ell_asm,
+                                                              const uint16_t *ell_pos, const int32_t *inc_off,
                                                               const uint32_t *inc, const int32_t *conn, const double2 *xy,
                                                               int64_t N, int32_t cap, int32_t img_pieces, int32_t segs,
                                                               double nu, double youngs, double thick, double *kval)
 {
     extern __shared__ __attribute__((aligned(16))) double2 s_asm[];
     double2 *s_xy = s_asm;                                   // [cap] coordinates of the tile's owned + halo nodes
-    int32_t *s_cid = (int32_t *)(s_xy + cap);                // [cap] their caller ids
+    int32_t *s_cid = (int32_t *)(s_xy + cap);                // [B] caller ids of the owned nodes
     double2 *s_cc = s_xy + img_pieces;                       // [2][256] the lanes' c-side blocks (top piece, bottom piece)
     double2 *s_dd = s_cc + 2 * kFanThreads;                  // [2][256] the lanes' diagonal shares
-    int32_t *s_col = (int32_t *)(s_dd + 2 * kFanThreads);    // [256] lane k of a node: the row's k-th column
-    int32_t *s_big = s_col + kFanThreads;                    // [B] rows left to the workgroup: caller id, or -1
+    int32_t *s_big = (int32_t *)(s_dd + 2 * kFanThreads);    // [B] rows left to the workgroup: caller id, or -1
     const int lane = threadIdx.x, k = lane & (kFanLanes - 1), gbase = lane & ~(kFanLanes - 1);
     // `segs` workgroups share a tile (each stages the whole image and takes B / segs of its row nodes): meshes of few
     // tiles still fill the chip
     const int32_t t = blockIdx.x / segs, seg = blockIdx.x % segs;
     const int32_t lfirst = seg * (B / segs), lend = lfirst + B / segs;
-    // ---- the tile's image: coordinates and caller ids of its owned and halo nodes
+    // ---- the tile's image: coordinates of its owned and halo nodes, caller ids of the owned ones
     const int32_t hoff = tile_hoff[t], nh = tile_hoff[t + 1] - hoff;
     bool in_range = true;
     for (int32_t l = lane; l < B; l += kFanThreads) {
@@ -570,71 +587,71 @@ __global__ void __launch_bounds__(kFanThreads) k_assemble_fan(const int32_t *bco
     for (int32_t h = lane; h < nh; h += kFanThreads) {
         const double2 c = halo_xy[hoff + h];
         s_xy[B + h] = c;
-        s_cid[B + h] = (int32_t)perm[halo_g[hoff + h]];
         in_range &= coord_in_range(c.x) && coord_in_range(c.y);
     }
-    const bool sane = __syncthreads_and(in_range ? 1 : 0) != 0;
     double D[9];
     stress_strain(nu, youngs, D);
+#pragma unroll
+    for (int m = 0; m < 9; ++m) in_range &= fabs(D[m]) < 1e60; // false for NaN as well
+    in_range &= fabs(thick) < 1e30;
+    const bool sane = __syncthreads_and(in_range ? 1 : 0) != 0;
     const int32_t td = tile_deg[t];
     const uint32_t *table = ell_asm + tile_off[t];
+    const uint16_t *ptable = ell_pos + tile_off[t];
     bool any_big = false;
     constexpr int kStep = kFanThreads / kFanLanes; // nodes per pass
-    // Software pipeline over the passes: while pass n is evaluated, the row pointers and the corner word of pass n + 1 are
-    // in flight, and the row's columns of pass n + 1 are requested at the end of pass n (they need its row pointer) -- they
-    // are only used after the evaluation, for the positions of the finished blocks.  No global latency sits on the path
-    // of a wave; 16 waves per CU cover the rest.
+    // Software pipeline over the passes: the row pointers and the two table words of pass n + 1 are requested at the top of
+    // pass n -- unconditionally, from a clamped node, so that no branch sits between a load and its first use (the
+    // compiler drains the memory counter at every join a load crosses: measured, the conditional form of this fetch waited
+    // for its own loads on the spot and for the previous pass's stores with them, ~3 us per pass for 0.4 us of
+    // arithmetic) -- and they are collected after the evaluation, BEFORE this pass's stores are issued: the counter is
+    // in-order, so a wait placed after the stores would wait for their acknowledgements too.
     struct Row {
-        int32_t i, p, cnt;
-        uint32_t w;
+        int32_t i, p, pe;
+        uint32_t w, pos;
     };
+    const int32_t nvalid = (int32_t)((N - (int64_t)t * B) < (int64_t)B ? (N - (int64_t)t * B) : (int64_t)B);
+    const int32_t llast = (lend < nvalid ? lend : nvalid) - 1; // last node of this segment that exists
+    const int kk = k < td ? k : td - 1; // every word of a node carries the diagonal's position: lanes beyond the tile's
+                                        // row length (they sum diagonal entries, see below) read it from the last slot
     auto fetch = [&](int32_t l) {
-        Row r = {-1, 0, 0, 0xffffffffu};
-        if ((int64_t)t * B + l < N && l < lend) {
-            r.i = s_cid[l];
-            r.p = bptr[r.i];
-            r.cnt = bptr[r.i + 1] - r.p; // 0: a row this rank does not keep (several GPUs)
-            if (k < td) r.w = table[(int64_t)k * B + l];
-        }
+        const int32_t lcl = l <= llast ? l : llast;
+        Row r;
+        r.i = s_cid[lcl];
+        r.p = bptr[r.i];
+        r.pe = bptr[r.i + 1];
+        r.w = table[(int64_t)kk * B + lcl];
+        r.pos = ptable[(int64_t)kk * B + lcl];
         return r;
     };
-    Row cur = fetch(lfirst + (lane >> 3));
-    int32_t colk = (cur.cnt > 0 && cur.cnt <= kFanLanes && k < cur.cnt) ? bcol[cur.p + k] : 0x7fffffff;
-    for (int32_t l0 = lfirst; l0 < lend; l0 += kStep) {
-        const int32_t l = l0 + (lane >> 3); // this lane's node inside the tile
-        const Row nxt = fetch(l + kStep);   // pass n + 1: in flight during the evaluation below
-        const int32_t i = cur.i, p = cur.p, cnt = cur.cnt;
-        const uint32_t w = cur.w;
-        const bool live = w != 0xffffffffu;
-        // bit 15: the node cannot be assembled triangle by triangle (every word of the node carries it)
-        const bool fanrow = live && cnt > 0 && cnt <= kFanLanes && !((w >> 15) & 1u);
-        const uint32_t lb = live ? (w & 0xfffu) : 0u, lc = live ? ((w >> 16) & 0xfffu) : 0u;
-        double dgc[4] = {0.0, 0.0, 0.0, 0.0}, kbv[4] = {0.0, 0.0, 0.0, 0.0}, kcv[4] = {0.0, 0.0, 0.0, 0.0};
-        int32_t ib = 0, ic = 0;
-        if (fanrow) {
-            ib = s_cid[lb];
-            ic = s_cid[lc];
-            asm_fan_blocks((int)((w >> 12) & 3u), s_xy[l], s_xy[lb], s_xy[lc], D, thick, sane, dgc, kbv, kcv);
-        }
-        s_col[lane] = colk;
-        s_cc[lane] = make_double2(kcv[0], kcv[1]); // [piece][lane]: consecutive lanes, consecutive 16-byte pieces
-        s_cc[kFanThreads + lane] = make_double2(kcv[2], kcv[3]);
-        s_dd[lane] = make_double2(dgc[0], dgc[1]);
-        s_dd[kFanThreads + lane] = make_double2(dgc[2], dgc[3]);
-        const unsigned long long livemask = __ballot(fanrow ? 1 : 0);
-        wave_lds_sync();
-        if (fanrow) {
-            const int4 c03 = *(const int4 *)(s_col + gbase), c47 = *(const int4 *)(s_col + gbase + 4);
-            const int32_t gc[8] = {c03.x, c03.y, c03.z, c03.w, c47.x, c47.y, c47.z, c47.w};
+    if (td > 0 && llast >= lfirst) {
+        Row cur = fetch(lfirst + (lane >> 3));
+        __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): the loop is entered with nothing in flight, as it is re-entered
+        for (int32_t l0 = lfirst; l0 < lend; l0 += kStep) {
+            const int32_t l = l0 + (lane >> 3); // this lane's node inside the tile
+            const Row nxt = fetch(l + kStep);   // pass n + 1: in flight during the evaluation below
+            const bool valid = l <= llast;
+            const int32_t i = valid ? cur.i : -1, p = cur.p;
+            const int32_t cnt = valid ? cur.pe - cur.p : 0; // 0: a row this rank does not keep (several GPUs)
+            const uint32_t w = (valid && k < td) ? cur.w : 0xffffffffu, pos = cur.pos;
+            const bool live = w != 0xffffffffu;
+            // bit 15: the node cannot be assembled triangle by triangle (every word of the node carries it)
+            const bool fanrow = live && cnt > 0 && !((w >> 15) & 1u);
+            const uint32_t lb = live ? (w & 0xfffu) : 0u, lc = live ? ((w >> 16) & 0xfffu) : 0u;
+            double dgc[4] = {0.0, 0.0, 0.0, 0.0}, kbv[4] = {0.0, 0.0, 0.0, 0.0}, kcv[4] = {0.0, 0.0, 0.0, 0.0};
+            if (fanrow) asm_fan_blocks((int)((w >> 12) & 3u), s_xy[l], s_xy[lb], s_xy[lc], D, thick, sane, dgc, kbv, kcv);
+            s_cc[lane] = make_double2(kcv[0], kcv[1]); // [piece][lane]: consecutive lanes, consecutive 16-byte pieces
+            s_cc[kFanThreads + lane] = make_double2(kcv[2], kcv[3]);
+            s_dd[lane] = make_double2(dgc[0], dgc[1]);
+            s_dd[kFanThreads + lane] = make_double2(dgc[2], dgc[3]);
+            // the node's first lane holds its first triangle: a row with any block has one, and it tells whether the row is a fan
+            const bool rowfan = ((__ballot(fanrow ? 1 : 0) >> (gbase & 63)) & 1ull) != 0;
+            wave_lds_sync();
             double *r0 = kval + 4 * (int64_t)p, *r1 = r0 + 2 * cnt;
-            int kb_pos = 0, kc_pos = 0; // positions of b and c among the row's ascending columns
-#pragma unroll
-            for (int j = 0; j < kFanLanes; ++j) {
-                kb_pos += gc[j] < ib ? 1 : 0;
-                kc_pos += gc[j] < ic ? 1 : 0;
-            }
+            // positions of b and c among the row's ascending columns: from the symbolic phase (k_fill_ell16)
+            const int kb_pos = (int)(pos & 15u), kc_pos = (int)((pos >> 4) & 15u);
             double t0 = 0.0 + kbv[0], t1 = 0.0 + kbv[1], t2 = 0.0 + kbv[2], t3 = 0.0 + kbv[3];
-            if (w >> 31) { // the other side of the edge a-b: the triangle whose c is this one's b
+            if (fanrow && (w >> 31)) { // the other side of the edge a-b: the triangle whose c is this one's b
                 const int pj = gbase + (int)((w >> 28) & 7u);
                 const double2 q0 = s_cc[pj], q1 = s_cc[kFanThreads + pj];
                 t0 = t0 + q0.x;
@@ -642,36 +659,42 @@ __global__ void __launch_bounds__(kFanThreads) k_assemble_fan(const int32_t *bco
                 t2 = t2 + q1.x;
                 t3 = t3 + q1.y;
             }
-            *(double2 *)(r0 + 2 * kb_pos) = make_double2(t0, t1);
-            *(double2 *)(r1 + 2 * kb_pos) = make_double2(t2, t3);
-            if ((w >> 14) & 1u) { // c has no b-side triangle: the open end of a boundary fan
-                *(double2 *)(r0 + 2 * kc_pos) = make_double2(0.0 + kcv[0], 0.0 + kcv[1]);
-                *(double2 *)(r1 + 2 * kc_pos) = make_double2(0.0 + kcv[2], 0.0 + kcv[3]);
-            }
-            if (k == 0) { // the diagonal: the triangles' shares in ascending element order (slot order), from 0.0
-                const unsigned mine = (unsigned)((livemask >> (gbase & 63)) & 0xffull);
-                int kd = 0;
-                double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+            double dsum = 0.0;
+            if (rowfan && k < 4) {
+                // the diagonal: the triangles' shares in ascending element order (slot order), from 0.0; lane k of the
+                // node sums entry k of the block.  Lanes without a triangle left +0.0 in their slots, and a sum that
+                // starts from +0.0 never becomes -0.0 (x + y = -0.0 only for x = y = -0.0): their shares change nothing.
+                const double *dd = (const double *)(s_dd + (k >> 1) * kFanThreads + gbase) + (k & 1);
 #pragma unroll
-                for (int j = 0; j < kFanLanes; ++j) {
-                    kd += gc[j] < i ? 1 : 0;
-                    if ((mine >> j) & 1u) {
-                        const double2 q0 = s_dd[gbase + j], q1 = s_dd[kFanThreads + gbase + j];
-                        d0 += q0.x;
-                        d1 += q0.y;
-                        d2 += q1.x;
-                        d3 += q1.y;
-                    }
-                }
-                *(double2 *)(r0 + 2 * kd) = make_double2(d0, d1);
-                *(double2 *)(r1 + 2 * kd) = make_double2(d2, d3);
+                for (int j = 0; j < kFanLanes; ++j) dsum += dd[2 * j];
             }
-        } else if (cnt > 0 && k == 0 && i >= 0) {
-            s_big[l] = i;
-            any_big = true;
+            // ---- the next pass's words are here by now (requested before the evaluation); collect them, then store
+            __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
+            cur = nxt;
+            __builtin_amdgcn_sched_barrier(0);
+            if (fanrow) {
+                *(double2 *)(r0 + 2 * kb_pos) = make_double2(t0, t1);
+                *(double2 *)(r1 + 2 * kb_pos) = make_double2(t2, t3);
+                if ((w >> 14) & 1u) { // c has no b-side triangle: the open end of a boundary fan
+                    *(double2 *)(r0 + 2 * kc_pos) = make_double2(0.0 + kcv[0], 0.0 + kcv[1]);
+                    *(double2 *)(r1 + 2 * kc_pos) = make_double2(0.0 + kcv[2], 0.0 + kcv[3]);
+                }
+            }
+            if (rowfan && k < 4) {
+                ((k >> 1) ? r1 : r0)[2 * (int)((pos >> 8) & 15u) + (k & 1)] = dsum;
+            } else if (!rowfan && cnt > 0 && k == 0 && i >= 0) {
+                s_big[l] = i;
+                any_big = true;
+            }
         }
-        cur = nxt;
-        colk = (cur.cnt > 0 && cur.cnt <= kFanLanes && k < cur.cnt) ? bcol[cur.p + k] : 0x7fffffff;
+    } else if (llast >= lfirst) { // a tile without a single triangle: whatever rows its nodes have go to the workgroup
+        for (int32_t l = lfirst + lane; l <= llast; l += kFanThreads) {
+            const int32_t i = s_cid[l];
+            if (bptr[i + 1] - bptr[i] > 0) {
+                s_big[l] = i;
+                any_big = true;
+            }
+        }
     }
     // rows the fan scheme did not take: the whole workgroup, one thread per block, k_assemble_rows arithmetic
     if (!__syncthreads_or(any_big ? 1 : 0)) return;
@@ -712,34 +735,34 @@ __global__ void __launch_bounds__(kFanThreads) k_assemble_fan(const int32_t *bco
     }
 }
 
-static int32_t asm_img_pieces(int32_t cap) { return (cap * 20 + 15) / 16; } // 16-byte pieces of the staged image
+static int32_t asm_img_pieces(int32_t cap, int32_t B) { return cap + (B * 4 + 15) / 16; } // 16-byte pieces of the staged image
 
 size_t assemble_ctiles_lds(int32_t B, int32_t cap)
 {
-    return (size_t)asm_img_pieces(cap) * 16 + (size_t)kFanThreads * (64 + 4) + (size_t)B * 4;
+    return (size_t)asm_img_pieces(cap, B) * 16 + (size_t)kFanThreads * 64 + (size_t)B * 4;
 }
 
 bool assemble_ctiles(const int32_t *bcol, const int32_t *bptr, const uint32_t *perm, const double *xyP,
-                     const double *halo_xy, const int32_t *halo_g, const int32_t *tile_hoff, const int32_t *tile_deg,
-                     const int64_t *tile_off, const uint32_t *ell_asm, const int32_t *inc_off, const uint32_t *inc,
+                     const double *halo_xy, const int32_t *tile_hoff, const int32_t *tile_deg, const int64_t *tile_off,
+                     const uint32_t *ell_asm, const uint16_t *ell_pos, const int32_t *inc_off, const uint32_t *inc,
                      const int32_t *conn, const double *xy, int64_t N, int32_t B, int32_t T, int32_t cap, double nu,
                      double youngs, double thick, double *kval, hipStream_t s)
 {
     const size_t lds = assemble_ctiles_lds(B, cap);
     if ((B != 256 && B != 512) || cap > 4096 || lds > 64 * 1024) return false; // 12-bit local ids; the image fits the LDS
-    const int32_t img = asm_img_pieces(cap);
+    const int32_t img = asm_img_pieces(cap, B);
     // workgroups per tile: at least ~4 per CU on small meshes (measured at 982 tiles: 1 per tile 64.2 us, 2: 66.5, 4: 70.2)
     int32_t segs = 1;
     while ((int64_t)T * segs < 1024 && B / (2 * segs) >= kFanThreads / kFanLanes) segs *= 2;
     if (const char *e = getenv("MAG_TUNE_ASM_SEGS")) segs = std::max(1, std::min(atoi(e), B / (kFanThreads / kFanLanes)));
     if (B == 256)
         k_assemble_fan<256><<<T * segs, kFanThreads, lds, s>>>(
-            bcol, bptr, perm, (const double2 *)xyP, (const double2 *)halo_xy, halo_g, tile_hoff, tile_deg, tile_off,
-            ell_asm, inc_off, inc, conn, (const double2 *)xy, N, cap, img, segs, nu, youngs, thick, kval);
+            bcol, bptr, perm, (const double2 *)xyP, (const double2 *)halo_xy, tile_hoff, tile_deg, tile_off, ell_asm,
+            ell_pos, inc_off, inc, conn, (const double2 *)xy, N, cap, img, segs, nu, youngs, thick, kval);
     else
         k_assemble_fan<512><<<T * segs, kFanThreads, lds, s>>>(
-            bcol, bptr, perm, (const double2 *)xyP, (const double2 *)halo_xy, halo_g, tile_hoff, tile_deg, tile_off,
-            ell_asm, inc_off, inc, conn, (const double2 *)xy, N, cap, img, segs, nu, youngs, thick, kval);
+            bcol, bptr, perm, (const double2 *)xyP, (const double2 *)halo_xy, tile_hoff, tile_deg, tile_off, ell_asm,
+            ell_pos, inc_off, inc, conn, (const double2 *)xy, N, cap, img, segs, nu, youngs, thick, kval);
     return true;
 }
 

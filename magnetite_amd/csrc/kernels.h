@@ -45,7 +45,7 @@ void halo_unique(const uint64_t *keys, const int32_t *head, const int32_t *blk, 
 // halo B + rank in halo_g[tile_hoff[t]..tile_hoff[t+1])
 void fill_ell16(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn, const int32_t *iperm,
                 const int32_t *tile_deg, const int64_t *tile_off, const int32_t *tile_hoff, const int32_t *halo_g,
-                int64_t N, int32_t B, int32_t T, uint32_t *ell, uint32_t *ell_asm, hipStream_t s);
+                int64_t N, int32_t B, int32_t T, uint32_t *ell, uint32_t *ell_asm, uint16_t *ell_pos, hipStream_t s);
 // halo_xy[i] = xyP[halo_g[i]]
 void halo_coords(const int32_t *halo_g, const double *xyP, int64_t n, double *halo_xy, hipStream_t s);
 // CSR pattern: 9 (row node, col node) pairs per element, key = row<<32 | col, val = 9e + 3a + b
@@ -102,8 +102,8 @@ void assemble_tiles(const int32_t *bcol, const int32_t *bptr, const int32_t *inc
 // when a tile's image does not fit one CU's LDS (the caller then uses assemble_tiles)
 size_t assemble_ctiles_lds(int32_t B, int32_t cap); // dynamic LDS of k_assemble_fan for B-node tiles with an image of `cap` nodes
 bool assemble_ctiles(const int32_t *bcol, const int32_t *bptr, const uint32_t *perm, const double *xyP,
-                     const double *halo_xy, const int32_t *halo_g, const int32_t *tile_hoff, const int32_t *tile_deg,
-                     const int64_t *tile_off, const uint32_t *ell_asm, const int32_t *inc_off, const uint32_t *inc,
+                     const double *halo_xy, const int32_t *tile_hoff, const int32_t *tile_deg, const int64_t *tile_off,
+                     const uint32_t *ell_asm, const uint16_t *ell_pos, const int32_t *inc_off, const uint32_t *inc,
                      const int32_t *conn, const double *xy, int64_t N, int32_t B, int32_t T, int32_t cap, double nu,
                      double youngs, double thick, double *kval, hipStream_t s);
 // solver.rs:365-404,427-432: b[row] = sum_{known cols, ascending} -(K*u) + f  (0 on prescribed rows),

@@ -323,7 +323,7 @@ __global__ void __launch_bounds__(256) k_fill_ell16(const int32_t *inc_off, cons
                                                     const int32_t *iperm, const int32_t *tile_deg,
                                                     const int64_t *tile_off, const int32_t *tile_hoff,
                                                     const int32_t *halo_g, int64_t N, int32_t B, uint32_t *ell,
-                                                    uint32_t *ell_asm)
+                                                    uint32_t *ell_asm, uint16_t *ell_pos)
 {
     const int32_t t = blockIdx.x;
     const int32_t td = tile_deg[t];
@@ -334,6 +334,7 @@ __global__ void __launch_bounds__(256) k_fill_ell16(const int32_t *inc_off, cons
     // the assembly's copy (k_assemble_fan, exact.hip): the same ids with the node's corner label and the pairing of the
     // node's triangles in the spare bits; it stays as written here, while `ell` is rewritten into ring form by k_ring16
     uint32_t *dst_asm = ell_asm ? ell_asm + tile_off[t] : nullptr;
+    uint16_t *dst_pos = ell_asm ? ell_pos + tile_off[t] : nullptr;
     for (int l = threadIdx.x; l < B; l += 256) {
         const int64_t i = (int64_t)base + l;
         int32_t o = 0, d = 0;
@@ -383,17 +384,43 @@ __global__ void __launch_bounds__(256) k_fill_ell16(const int32_t *inc_off, cons
             openc |= (npc == 0 ? 1u : 0u) << k;
             odd |= lbk == lck || lbk == (uint32_t)l || lck == (uint32_t)l || npb > 1 || npc > 1;
         }
+        // Where the blocks go: the row's columns are the node and its neighbours in ascending CALLER id (k_pattern_rows), and
+        // in a fan every neighbour is the b of exactly one triangle or the c of an open end, so the position of a column is a
+        // count over those: kb (bits 0-3) for triangle k's b, kc (4-7) for its c, kd (8-11, in every word of the node) for
+        // the diagonal.  At most eight triangles, hence at most ten columns.
+        int32_t cb[8], cc[8], self = 0;
+        uint32_t lab[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            cb[k] = cc[k] = 0x7fffffff;
+            lab[k] = 0;
+            if (ws[k] == 0xffffffffu) continue;
+            const uint32_t v = inc[o + k];
+            const uint32_t e = v / 3u, c = v - 3u * e;
+            const uint32_t c1 = c == 2 ? 0 : c + 1, c2 = c1 == 2 ? 0 : c1 + 1;
+            lab[k] = c;
+            self = conn[3 * (int64_t)e + c];
+            cb[k] = conn[3 * (int64_t)e + c1];
+            cc[k] = ((openc >> k) & 1u) ? conn[3 * (int64_t)e + c2] : 0x7fffffff; // counted only where it is nobody's b
+        }
+        auto before = [&](int32_t x) { // columns of the row with a caller id below x
+            int n = self < x ? 1 : 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) n += (cb[j] < x ? 1 : 0) + (cc[j] < x ? 1 : 0);
+            return (uint32_t)n;
+        };
+        const uint32_t kd = before(self);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             if (k >= td) break;
-            uint32_t wa = 0xffffffffu;
+            uint32_t wa = 0xffffffffu, wp = kd << 8;
             if (ws[k] != 0xffffffffu) {
-                const uint32_t v = inc[o + k];
-                const uint32_t c = v - 3u * (v / 3u);
-                wa = (ws[k] & 0xffffu) | (c << 12) | (((openc >> k) & 1u) << 14) | ((odd ? 1u : 0u) << 15) |
+                wa = (ws[k] & 0xffffu) | (lab[k] << 12) | (((openc >> k) & 1u) << 14) | ((odd ? 1u : 0u) << 15) |
                      ((ws[k] >> 16) << 16) | (((pjs >> (3 * k)) & 7u) << 28) | (((has >> k) & 1u) << 31);
+                wp |= (before(cb[k]) & 15u) | ((((openc >> k) & 1u) ? before(cc[k]) & 15u : 0u) << 4);
             }
             dst_asm[(int64_t)k * B + l] = wa;
+            dst_pos[(int64_t)k * B + l] = (uint16_t)wp;
         }
         for (int k = 8; k < td; ++k) { // a node of more than eight triangles is flagged (odd): only ids and label matter
             uint32_t wa = 0xffffffffu;
@@ -403,15 +430,17 @@ __global__ void __launch_bounds__(256) k_fill_ell16(const int32_t *inc_off, cons
                 wa = (wk & 0xffffu) | ((v - 3u * (v / 3u)) << 12) | (1u << 15) | ((wk >> 16) << 16);
             }
             dst_asm[(int64_t)k * B + l] = wa;
+            dst_pos[(int64_t)k * B + l] = 0;
         }
     }
 }
 
 void fill_ell16(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn, const int32_t *iperm,
                 const int32_t *tile_deg, const int64_t *tile_off, const int32_t *tile_hoff, const int32_t *halo_g,
-                int64_t N, int32_t B, int32_t T, uint32_t *ell, uint32_t *ell_asm, hipStream_t s)
+                int64_t N, int32_t B, int32_t T, uint32_t *ell, uint32_t *ell_asm, uint16_t *ell_pos, hipStream_t s)
 {
-    k_fill_ell16<<<T, 256, 0, s>>>(inc_off, inc, conn, iperm, tile_deg, tile_off, tile_hoff, halo_g, N, B, ell, ell_asm);
+    k_fill_ell16<<<T, 256, 0, s>>>(inc_off, inc, conn, iperm, tile_deg, tile_off, tile_hoff, halo_g, N, B, ell, ell_asm,
+                                   ell_pos);
 }
 
 // Ring form of the tile-local table.  fill_ell16 leaves one word (lb | lc << 16) per incident triangle (a, b, c);
