@@ -416,34 +416,40 @@ void assemble_tiles(const int32_t *bcol, const int32_t *bptr, const int32_t *inc
 // thread-per-row kernel from the CG tiles and storing row-wise brought 76 -> 70 us; what remained was the latency of a
 // workgroup's serial phases with two waves per SIMD.  This kernel drops the accumulators:
 //
-//   ONE LANE PER (row node a, incident triangle (a, b, c)), eight lanes per node -- a wave holds eight nodes.
+//   ONE LANE PER (row node a, incident triangle (a, b, c)), eight lanes per node -- a wave holds eight nodes (six lanes and
+//   ten nodes in tiles where no node has more than six triangles: the rule on structured meshes).
 //
 // The ordering phase has already built, per tile of B consecutive Hilbert nodes, what the gathers look up: the tile's owned
 // + halo coordinates as two contiguous runs (xyP, halo_xy) and, per node, one word per incident element in ascending
 // element order -- the two OTHER corners as tile-local ids (symbolic.hip, k_fill_ell16; kept for this kernel with the
 // node's corner label in the spare bits: lb | label << 12 | lc << 16, orientation a -> b -> c of the reference's vertex
-// order).  A lane evaluates its triangle once (asm_fan_blocks: the rotated frame; only the ORDER in which solver.rs:187-193
-// sums the three products of the signed area depends on the label) and holds the three blocks of row a it contributes
-// to: the diagonal's share, the block of column b, the block of column c.  Then, per row:
+// order) plus, in a 16-bit companion word, WHERE the triangle's blocks go: the positions of b, of c and of the diagonal
+// among the row's columns (ascending caller id), counted once per mesh by the symbolic phase -- the kernel reads neither
+// the column indices nor any caller id but its own nodes'.  A lane evaluates its triangle once (asm_fan_blocks: the rotated
+// frame; only the ORDER in which solver.rs:187-193 sums the three products of the signed area depends on the label) and
+// holds the three blocks of row a it contributes to: the diagonal's share, the block of column b, the block of column c.
+// Then, per row:
 //   * an off-diagonal block (a, n) receives at most two contributions in a manifold mesh -- from the triangle that has n
 //     as its b and the one that has it as its c, the two sides of the edge a-n.  The reference adds them in ascending
 //     element order, (0.0 + c1) + c2; IEEE addition is commutative (and (0.0 + x) + y = (0.0 + y) + x also when signed
-//     zeros are involved), so the b-side lane fetches its partner's c-side block from LDS, forms (0.0 + own) + partner's
-//     and stores the finished block; a c with no b-side partner (the open end of a boundary fan) is stored by its own lane;
+//     zeros are involved), so the b-side lane fetches its partner's c-side block from LDS and forms (0.0 + own) + partner's;
+//     a c with no b-side partner (the open end of a boundary fan) is finished by its own lane;
 //   * the diagonal block receives one contribution per triangle and there the order does matter: the lanes of a node hold
-//     their triangles in ascending element order (slot order of the table), the node's first lane adds the shares up from
-//     LDS in that order, starting from 0.0;
-//   * the row's columns are loaded by the node's lanes (lane k its k-th column: one 32-byte run), and every store goes into
-//     the row's one contiguous run of 32 * cnt bytes: reads and writes are row-wise by construction.
-// No accumulators: the image (20 bytes per staged node) and 64 bytes per lane of exchange space make ~33 KB of LDS per
-// 256-thread workgroup -- four workgroups (16 waves) per CU.  The seven quotients of `B /= 2A` share their denominator:
+//     their triangles in ascending element order (slot order of the table); four lanes of the node add up one entry of the
+//     block each, from LDS, in that order, starting from 0.0;
+//   * the finished 16-byte pieces are put where they belong in a staging copy of the node's run of K (its two rows are one
+//     contiguous run of 32 * cnt bytes) and the wave writes the runs out sixteen lanes per node: whole runs per store
+//     instruction.  (Stored piece by piece -- one 16-byte piece per triangle and instruction -- the kernel was bound by its
+//     3 M write requests of 37 bytes: same 48 us with the arithmetic removed, 36 us with the stores removed.)
+// No accumulators: the image (16 bytes per staged node, 4 per owned node) and 64 bytes per lane of exchange / staging
+// space make ~31 KB of LDS per 256-thread workgroup -- four workgroups (16 waves) per CU with the kernel's 110 VGPRs.  The seven quotients of `B /= 2A` share their denominator:
 // with r = RN(1 / 2A) (one true division) each quotient is x r corrected twice with exact FMA residuals (Markstein's
 // sequence, the one IA-64 and POWER divide with): RN(x / 2A), the reference's bits, in 5 instructions instead of a
 // ~13-instruction division each.  Valid while nothing under- or overflows and 2A's significand is not all ones:
 // guaranteed per tile by a range check of the staged coordinates (0 or 1e-150 < |c| < 1e30, so a non-zero difference is
 // >= 2e-166) and per element by 1e-40 < |2A| < 1e60; otherwise the true divisions run.  Under the same bounds (and
 // |D| < 1e60, |thickness| < 1e30) the terms with a structural zero of B or D are left out (see asm_fan_blocks).
-// Rows the scheme does not cover -- more than 8 triangles or 8 blocks, an edge with three or more triangles, an element
+// Rows the scheme does not cover -- more than 8 triangles, an edge with three or more triangles, an element
 // that lists a node twice -- are finished by the whole workgroup with the k_assemble_rows arithmetic (label order, true
 // divisions), as in k_assemble_tiles.  Tiles whose image does not fit fall back to k_assemble_tiles altogether.
 __device__ inline double div_shared(double x, double d, double r)
@@ -549,6 +555,7 @@ __device__ inline void wave_lds_sync()
 
 constexpr int kFanThreads = 256; // 32 nodes x 8 lanes per pass
 constexpr int kFanLanes = 8;     // lanes (triangles, columns) per node
+constexpr int kFanStage = 20;    // 16-byte pieces of staging per node: two rows of at most ten blocks
 
 template <int B>
 __global__ void __launch_bounds__(kFanThreads) k_assemble_fan(const int32_t *bcol, const int32_t *bptr, const uint32_t *perm,
@@ -558,7 +565,7 @@ __global__ void __launch_bounds__(kFanThreads) k_assemble_fan(const int32_t *bco
                                                               const uint16_t *ell_pos, const int32_t *inc_off,
                                                               const uint32_t *inc, const int32_t *conn, const double2 *xy,
                                                               int64_t N, int32_t cap, int32_t img_pieces, int32_t segs,
-                                                              double nu, double youngs, double thick, double *kval)
+                                                              int32_t six, double nu, double youngs, double thick, double *kval)
 {
     extern __shared__ __attribute__((aligned(16))) double2 s_asm[];
     double2 *s_xy = s_asm;                                   // [cap] coordinates of the tile's owned + halo nodes
@@ -566,7 +573,7 @@ __global__ void __launch_bounds__(kFanThreads) k_assemble_fan(const int32_t *bco
     double2 *s_cc = s_xy + img_pieces;                       // [2][256] the lanes' c-side blocks (top piece, bottom piece)
     double2 *s_dd = s_cc + 2 * kFanThreads;                  // [2][256] the lanes' diagonal shares
     int32_t *s_big = (int32_t *)(s_dd + 2 * kFanThreads);    // [B] rows left to the workgroup: caller id, or -1
-    const int lane = threadIdx.x, k = lane & (kFanLanes - 1), gbase = lane & ~(kFanLanes - 1);
+    const int lane = threadIdx.x;
     // `segs` workgroups share a tile (each stages the whole image and takes B / segs of its row nodes): meshes of few
     // tiles still fill the chip
     const int32_t t = blockIdx.x / segs, seg = blockIdx.x % segs;
@@ -599,7 +606,6 @@ __global__ void __launch_bounds__(kFanThreads) k_assemble_fan(const int32_t *bco
     const uint32_t *table = ell_asm + tile_off[t];
     const uint16_t *ptable = ell_pos + tile_off[t];
     bool any_big = false;
-    constexpr int kStep = kFanThreads / kFanLanes; // nodes per pass
     // Software pipeline over the passes: the row pointers and the two table words of pass n + 1 are requested at the top of
     // pass n -- unconditionally, from a clamped node, so that no branch sits between a load and its first use (the
     // compiler drains the memory counter at every join a load crosses: measured, the conditional form of this fetch waited
@@ -612,25 +618,35 @@ __global__ void __launch_bounds__(kFanThreads) k_assemble_fan(const int32_t *bco
     };
     const int32_t nvalid = (int32_t)((N - (int64_t)t * B) < (int64_t)B ? (N - (int64_t)t * B) : (int64_t)B);
     const int32_t llast = (lend < nvalid ? lend : nvalid) - 1; // last node of this segment that exists
-    const int kk = k < td ? k : td - 1; // every word of a node carries the diagonal's position: lanes beyond the tile's
-                                        // row length (they sum diagonal entries, see below) read it from the last slot
-    auto fetch = [&](int32_t l) {
-        const int32_t lcl = l <= llast ? l : llast;
-        Row r;
-        r.i = s_cid[lcl];
-        r.p = bptr[r.i];
-        r.pe = bptr[r.i + 1];
-        r.w = table[(int64_t)kk * B + lcl];
-        r.pos = ptable[(int64_t)kk * B + lcl];
-        return r;
-    };
-    if (td > 0 && llast >= lfirst) {
-        Row cur = fetch(lfirst + (lane >> 3));
+    // LANES lanes per node: eight in general; six when no node of the tile has more triangles (the rule on structured
+    // meshes: a closed fan of valence 6) -- ten nodes per wave instead of eight, four idle lanes instead of a quarter.
+    auto run = [&](auto lanes_c) {
+        constexpr int LANES = decltype(lanes_c)::value, NPW = 64 / LANES; // nodes per wave
+        constexpr int kStep = (kFanThreads / 64) * NPW;                   // nodes per pass
+        const int nw = (lane & 63) / LANES, k = (lane & 63) - nw * LANES, gbase = lane - k;
+        const bool lane_used = nw < NPW;
+        const int wl = lane & 63, gb = gbase & 63;
+        double2 *wreg = s_cc + (lane >> 6) * 256; // this wave's exchange area: 4 x 64 pieces (s_cc and s_dd are contiguous)
+        int2 *hdr = (int2 *)(wreg + NPW * kFanStage); // per node of the wave: start of its run of K, blocks in its rows
+        const int32_t lnode = (lane >> 6) * NPW + nw; // this lane's node inside a pass
+        const int kk = k < td ? k : td - 1; // every word of a node carries the diagonal's position: lanes beyond the tile's
+                                            // row length (they sum diagonal entries, see below) read it from the last slot
+        auto fetch = [&](int32_t l) {
+            const int32_t lcl = l <= llast ? l : llast;
+            Row r;
+            r.i = s_cid[lcl];
+            r.p = bptr[r.i];
+            r.pe = bptr[r.i + 1];
+            r.w = table[(int64_t)kk * B + lcl];
+            r.pos = ptable[(int64_t)kk * B + lcl];
+            return r;
+        };
+        Row cur = fetch(lfirst + lnode);
         __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0): the loop is entered with nothing in flight, as it is re-entered
         for (int32_t l0 = lfirst; l0 < lend; l0 += kStep) {
-            const int32_t l = l0 + (lane >> 3); // this lane's node inside the tile
+            const int32_t l = l0 + lnode; // this lane's node inside the tile
             const Row nxt = fetch(l + kStep);   // pass n + 1: in flight during the evaluation below
-            const bool valid = l <= llast;
+            const bool valid = l <= llast && lane_used;
             const int32_t i = valid ? cur.i : -1, p = cur.p;
             const int32_t cnt = valid ? cur.pe - cur.p : 0; // 0: a row this rank does not keep (several GPUs)
             const uint32_t w = (valid && k < td) ? cur.w : 0xffffffffu, pos = cur.pos;
@@ -639,54 +655,92 @@ __global__ void __launch_bounds__(kFanThreads) k_assemble_fan(const int32_t *bco
             const bool fanrow = live && cnt > 0 && !((w >> 15) & 1u);
             const uint32_t lb = live ? (w & 0xfffu) : 0u, lc = live ? ((w >> 16) & 0xfffu) : 0u;
             double dgc[4] = {0.0, 0.0, 0.0, 0.0}, kbv[4] = {0.0, 0.0, 0.0, 0.0}, kcv[4] = {0.0, 0.0, 0.0, 0.0};
-            if (fanrow) asm_fan_blocks((int)((w >> 12) & 3u), s_xy[l], s_xy[lb], s_xy[lc], D, thick, sane, dgc, kbv, kcv);
-            s_cc[lane] = make_double2(kcv[0], kcv[1]); // [piece][lane]: consecutive lanes, consecutive 16-byte pieces
-            s_cc[kFanThreads + lane] = make_double2(kcv[2], kcv[3]);
-            s_dd[lane] = make_double2(dgc[0], dgc[1]);
-            s_dd[kFanThreads + lane] = make_double2(dgc[2], dgc[3]);
+            if (fanrow) {
+                asm_fan_blocks((int)((w >> 12) & 3u), s_xy[l], s_xy[lb], s_xy[lc], D, thick, sane, dgc, kbv, kcv);
+                wreg[wl] = make_double2(kcv[0], kcv[1]); // the c-side block: top piece, bottom piece
+                wreg[64 + wl] = make_double2(kcv[2], kcv[3]);
+            }
+            wreg[128 + wl] = make_double2(dgc[0], dgc[1]); // every lane: the diagonal's sum runs over all the node's lanes
+            wreg[192 + wl] = make_double2(dgc[2], dgc[3]);
             // the node's first lane holds its first triangle: a row with any block has one, and it tells whether the row is a fan
-            const bool rowfan = ((__ballot(fanrow ? 1 : 0) >> (gbase & 63)) & 1ull) != 0;
+            const bool rowfan = ((__ballot(fanrow ? 1 : 0) >> gb) & 1ull) != 0;
             wave_lds_sync();
-            double *r0 = kval + 4 * (int64_t)p, *r1 = r0 + 2 * cnt;
             // positions of b and c among the row's ascending columns: from the symbolic phase (k_fill_ell16)
             const int kb_pos = (int)(pos & 15u), kc_pos = (int)((pos >> 4) & 15u);
-            double t0 = 0.0 + kbv[0], t1 = 0.0 + kbv[1], t2 = 0.0 + kbv[2], t3 = 0.0 + kbv[3];
-            if (fanrow && (w >> 31)) { // the other side of the edge a-b: the triangle whose c is this one's b
-                const int pj = gbase + (int)((w >> 28) & 7u);
-                const double2 q0 = s_cc[pj], q1 = s_cc[kFanThreads + pj];
-                t0 = t0 + q0.x;
-                t1 = t1 + q0.y;
-                t2 = t2 + q1.x;
-                t3 = t3 + q1.y;
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+            if (fanrow) {
+                t0 = 0.0 + kbv[0], t1 = 0.0 + kbv[1], t2 = 0.0 + kbv[2], t3 = 0.0 + kbv[3];
+                if (w >> 31) { // the other side of the edge a-b: the triangle whose c is this one's b
+                    const int pj = gb + (int)((w >> 28) & 7u);
+                    const double2 q0 = wreg[pj], q1 = wreg[64 + pj];
+                    t0 = t0 + q0.x;
+                    t1 = t1 + q0.y;
+                    t2 = t2 + q1.x;
+                    t3 = t3 + q1.y;
+                }
             }
             double dsum = 0.0;
             if (rowfan && k < 4) {
                 // the diagonal: the triangles' shares in ascending element order (slot order), from 0.0; lane k of the
                 // node sums entry k of the block.  Lanes without a triangle left +0.0 in their slots, and a sum that
                 // starts from +0.0 never becomes -0.0 (x + y = -0.0 only for x = y = -0.0): their shares change nothing.
-                const double *dd = (const double *)(s_dd + (k >> 1) * kFanThreads + gbase) + (k & 1);
+                const double *dd = (const double *)(wreg + 128 + (k >> 1) * 64 + gb) + (k & 1);
 #pragma unroll
-                for (int j = 0; j < kFanLanes; ++j) dsum += dd[2 * j];
+                for (int j = 0; j < LANES; ++j) dsum += dd[2 * j];
             }
+            // ---- the finished pieces go to the wave's staging area, laid out like the node's run of K: 2 cnt pieces of
+            // 16 bytes (row 2i: cnt blocks' top halves, row 2i + 1: their bottom halves).  It takes the exchange area's
+            // place: a wave's LDS operations execute in order, its reads above are served before these writes.
+            wave_lds_sync();
+            double2 *stage = wreg + nw * kFanStage;
+            if (fanrow) {
+                stage[kb_pos] = make_double2(t0, t1);
+                stage[cnt + kb_pos] = make_double2(t2, t3);
+                if ((w >> 14) & 1u) { // c has no b-side triangle: the open end of a boundary fan
+                    stage[kc_pos] = make_double2(0.0 + kcv[0], 0.0 + kcv[1]);
+                    stage[cnt + kc_pos] = make_double2(0.0 + kcv[2], 0.0 + kcv[3]);
+                }
+            }
+            if (rowfan && k < 4) ((double *)(stage + (k >> 1) * cnt + (int)((pos >> 8) & 15u)))[k & 1] = dsum;
+            if (k == 0 && lane_used) hdr[nw] = make_int2(p, rowfan ? cnt : 0);
+            wave_lds_sync();
             // ---- the next pass's words are here by now (requested before the evaluation); collect them, then store
             __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
             cur = nxt;
             __builtin_amdgcn_sched_barrier(0);
-            if (fanrow) {
-                *(double2 *)(r0 + 2 * kb_pos) = make_double2(t0, t1);
-                *(double2 *)(r1 + 2 * kb_pos) = make_double2(t2, t3);
-                if ((w >> 14) & 1u) { // c has no b-side triangle: the open end of a boundary fan
-                    *(double2 *)(r0 + 2 * kc_pos) = make_double2(0.0 + kcv[0], 0.0 + kcv[1]);
-                    *(double2 *)(r1 + 2 * kc_pos) = make_double2(0.0 + kcv[2], 0.0 + kcv[3]);
+            // Copy-out: sixteen lanes per node, a lane per piece -- every store instruction writes whole runs of K (four
+            // nodes' 32 cnt contiguous bytes each) instead of one 16-byte piece per triangle scattered over the rows.
+            // Measured on the 1M mesh with the piecewise stores: the kernel took the same 48 us with the arithmetic
+            // removed and 36 us with the stores removed -- 3 M write requests of 37 bytes on average for 111 MB.
+            bool longrow = false;
+#pragma unroll
+            for (int j = 0; j < (NPW + 3) / 4; ++j) {
+                const int node = 4 * j + (wl >> 4), piece = wl & 15;
+                const int2 h = node < NPW ? hdr[node] : make_int2(0, 0);
+                if (piece < 2 * h.y)
+                    *(double2 *)(kval + 4 * (int64_t)h.x + 2 * piece) = wreg[node * kFanStage + piece];
+                longrow |= h.y > 8;
+            }
+            if (__any(longrow ? 1 : 0)) { // rows of nine or ten blocks (open fans of seven or eight triangles): pieces 16-19
+#pragma unroll
+                for (int j = 0; j < (NPW + 3) / 4; ++j) {
+                    const int node = 4 * j + (wl >> 4), piece = 16 + (wl & 15);
+                    const int2 h = node < NPW ? hdr[node] : make_int2(0, 0);
+                    if (piece < 2 * h.y)
+                        *(double2 *)(kval + 4 * (int64_t)h.x + 2 * piece) = wreg[node * kFanStage + piece];
                 }
             }
-            if (rowfan && k < 4) {
-                ((k >> 1) ? r1 : r0)[2 * (int)((pos >> 8) & 15u) + (k & 1)] = dsum;
-            } else if (!rowfan && cnt > 0 && k == 0 && i >= 0) {
+            if (!rowfan && cnt > 0 && k == 0 && i >= 0) {
                 s_big[l] = i;
                 any_big = true;
             }
         }
+    }; // run
+    if (td > 0 && llast >= lfirst) {
+        if (td <= 6 && six)
+            run(std::integral_constant<int, 6>{});
+        else
+            run(std::integral_constant<int, 8>{});
     } else if (llast >= lfirst) { // a tile without a single triangle: whatever rows its nodes have go to the workgroup
         for (int32_t l = lfirst + lane; l <= llast; l += kFanThreads) {
             const int32_t i = s_cid[l];
@@ -751,18 +805,21 @@ bool assemble_ctiles(const int32_t *bcol, const int32_t *bptr, const uint32_t *p
     const size_t lds = assemble_ctiles_lds(B, cap);
     if ((B != 256 && B != 512) || cap > 4096 || lds > 64 * 1024) return false; // 12-bit local ids; the image fits the LDS
     const int32_t img = asm_img_pieces(cap, B);
-    // workgroups per tile: at least ~4 per CU on small meshes (measured at 982 tiles: 1 per tile 64.2 us, 2: 66.5, 4: 70.2)
+    // workgroups per tile: at least ~3 per CU on small meshes (measured at 982 tiles: 1 per tile 44.6 us, 2: 49.0; at
+    // 3911 tiles 1: 152, 2: 165)
     int32_t segs = 1;
-    while ((int64_t)T * segs < 1024 && B / (2 * segs) >= kFanThreads / kFanLanes) segs *= 2;
+    while ((int64_t)T * segs < 768 && B / (2 * segs) >= kFanThreads / kFanLanes) segs *= 2;
+    const char *e6 = getenv("MAG_TUNE_ASM_LANES"); // 8: never six lanes per node
+    const int32_t six = e6 && atoi(e6) == 8 ? 0 : 1;
     if (const char *e = getenv("MAG_TUNE_ASM_SEGS")) segs = std::max(1, std::min(atoi(e), B / (kFanThreads / kFanLanes)));
     if (B == 256)
         k_assemble_fan<256><<<T * segs, kFanThreads, lds, s>>>(
             bcol, bptr, perm, (const double2 *)xyP, (const double2 *)halo_xy, tile_hoff, tile_deg, tile_off, ell_asm,
-            ell_pos, inc_off, inc, conn, (const double2 *)xy, N, cap, img, segs, nu, youngs, thick, kval);
+            ell_pos, inc_off, inc, conn, (const double2 *)xy, N, cap, img, segs, six, nu, youngs, thick, kval);
     else
         k_assemble_fan<512><<<T * segs, kFanThreads, lds, s>>>(
             bcol, bptr, perm, (const double2 *)xyP, (const double2 *)halo_xy, tile_hoff, tile_deg, tile_off, ell_asm,
-            ell_pos, inc_off, inc, conn, (const double2 *)xy, N, cap, img, segs, nu, youngs, thick, kval);
+            ell_pos, inc_off, inc, conn, (const double2 *)xy, N, cap, img, segs, six, nu, youngs, thick, kval);
     return true;
 }
 
