@@ -231,7 +231,7 @@ def roofline_streaming(kind, E, N, ms_op, pmc, tile):
                        bytes_spmv(E, N) + 48.0 * N, "12E+50N (SpMV, SURVEY 8d) + 48N (p read, p and x written)", ms_op, pmc)
 
 
-def roofline_onchip(E, N, iters, ms_cg, pmc, tile):
+def roofline_onchip(E, N, iters, ms_cg, pmc, tile, edge_blocks=False):
     """k_cg_persist keeps the CG state in registers and LDS: HBM only sees the per-iteration exchange, so an HBM roof
     says nothing about it.  Its largest counted resource is fp64 vector issue (PMC: SQ_ACTIVE_INST_VALU), so it is
     priced against the fp64 vector peak with the ALGORITHMIC flops of the iterations it ran; the counted utilisations
@@ -239,7 +239,10 @@ def roofline_onchip(E, N, iters, ms_cg, pmc, tile):
     flops = flops_iteration(E, N) * iters
     tf = flops / (ms_cg * 1e-3) / 1e12
     d = {"kernel": "k_cg_persist<%d> (the whole CG solve in ONE launch: state resident in registers and LDS, grid-wide "
-                   "exchange by tagged granules every iteration)" % tile,
+                   "exchange by tagged granules every iteration; %s)"
+                   % (tile, "edge-block instantiation: six symmetric 2 x 2 blocks per node in registers" if edge_blocks
+                      else "triangle-walk instantiation: cached triangle weights"),
+         "edge_blocks": bool(edge_blocks),
          "bound": "valu-fp64", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
          "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "flops_per_launch": flops,
          "flops_formula": "(110E + 20N) x iterations (SURVEY 8d: ~110 flop per element-loop SpMV element + 10 flop per "
@@ -544,7 +547,8 @@ def main():
         if world > 1:  # the committed PMC passes are single-GPU runs of the single-GPU kernels: no counters for N > 1
             tile_key = "none"
         if kind == 2:
-            roofline = roofline_onchip(Eloc, Nloc, iters, st["ms_cg"], load_pmc(f"{tile_key}:kernel2"), args.tile)
+            roofline = roofline_onchip(Eloc, Nloc, iters, st["ms_cg"], load_pmc(f"{tile_key}:kernel2"), args.tile,
+                                       bool(st.get("edge_blocks", 0)))
         elif kind == 4:  # fp32 leg: value terms halved (r, q, p, x in and out 64N, coordinates 8N, mask 1N); no timing
             # hook of its own, so the launch time is the CG phase / iterations (graph gaps and early exits included)
             roofline = kernel_line("k_cg_fused32<%d> (whole CG iteration in one launch, fp32 state)" % args.tile,
@@ -593,8 +597,9 @@ def main():
                 bytes_iteration_unfused(E, N) * iters / (st["ms_cg"] * 1e-3) / 1e9 if st["ms_cg"] > 0 else None,
             "assembly_elements_per_sec": E / (asm_ms * 1e-3) if asm_ms > 0 else None,
             # numeric assembly (K_e + CSR rows per element tile + BC elimination) against the HBM roof with SURVEY 8(d)'s
-            # bytes; the kernel is gather-latency-bound, the CSR pattern is ms_csr_symbolic
-            "assembly": ({"kernel": "k_assemble_tiles + k_rhs_from_csr", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            # bytes (k_assemble_fan: fp64-issue-bound; MAG_TUNE_ASSEMBLY selects the older kernels); the
+            # CSR pattern is ms_csr_symbolic
+            "assembly": ({"kernel": "k_assemble_fan + k_rhs_from_csr", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                           "bytes": 12.0 * Eloc + 240.0 * Nloc, "bytes_formula": "12E+240N (SURVEY 8d), per-GPU share",
                           "ms": asm_ms, "achieved": (12.0 * Eloc + 240.0 * Nloc) / (asm_ms * 1e-3) / 1e9,
                           "frac": (12.0 * Eloc + 240.0 * Nloc) / (asm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}

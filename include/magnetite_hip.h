@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MAG_ABI_VERSION 3 /* 3: mag_stats gained exchange_timeout, best_param_mismatch */
+#define MAG_ABI_VERSION 4 /* 3: mag_stats gained exchange_timeout, best_param_mismatch; 4: edge_blocks */
 
 /* solver.rs:17-19 */
 #define MAG_DOF 2
@@ -190,6 +190,11 @@ typedef struct mag_stats {
                                     solve up to that iteration; 1 when the repeat took another kernel or exchange than the
                                     first pass, or its cost there is not the recorded best cost bit for bit --
                                     `final_cost` is then the cost of the iterate actually returned                  */
+    int32_t edge_blocks;    /* cg_kernel 2 only: 1 when the on-chip kernel ran its edge-block instantiation (every node's
+                               triangles folded into at most six symmetric 2 x 2 blocks held in registers: meshes whose
+                               nodes all carry one fan of at most six triangles, closed, or five, open), 0 when it walked
+                               the triangles (any other mesh)                                                       */
+    int32_t reserved0;
 } mag_stats;
 
 /* ---- lifecycle ------------------------------------------------------- */

@@ -85,6 +85,7 @@ struct mag_ctx {
     DevBuf scratch, small; // rocPRIM temp; small = bbox partials, bbox, err flag
     DevBuf sK0, sK1, sV0, sV1;
     DevBuf perm, iperm, xyP, maskP, deg, inc_off, inc, tile_deg, tile_rdeg, tile_cnt, tile_off, ell, ell_asm, ell_pos;
+    DevBuf kblocks; // on-chip CG, edge-block instantiation: the nodes' blocks (k_edge_blocks)
     bool asm_ctile = false; // K is assembled from the CG tiles (k_assemble_fan), ell_asm holds its corner words
     // tile-local numbering for the LDS-halo operator
     bool use_lds = false;
@@ -140,6 +141,7 @@ struct mag_ctx {
     double best_cost = 0.0;   // argmin's best_param bookkeeping, as the CG phase that just ran reported it
     long long best_iter = 0;
     bool persist_timed_out = false, exchange_timed_out = false;
+    bool edge_blocks = false; // the on-chip kernel of the last run was its edge-block instantiation (mag_stats.edge_blocks)
     // streaming kernels across GPUs: the per-iteration exchange through the device inboxes (k_stream_exchange) instead of
     // an all-reduce; si_failed: a wait ran out once, this context uses the all-reduce from then on
     bool si = false, si_failed = false;
@@ -434,7 +436,7 @@ int ensure_order(mag_ctx *ctx)
                          ctx->asm_ctile ? ctx->ell_pos.as<uint16_t>() : nullptr, s);
         HIPCHK(ctx->tile_rdeg.reserve(2 * 4 * ((size_t)T + 1)));
         magk::ring16(ctx->tile_deg.as<int32_t>(), ctx->tile_off.as<int64_t>(), B, T, ctx->ell.as<uint32_t>(),
-                     ctx->tile_rdeg.as<int32_t>(), s);
+                     ctx->tile_rdeg.as<int32_t>(), magk::persist_block_entries(), s);
         HIPCHK(ctx->tmeta.reserve(sizeof(magk::TileMeta) * (size_t)T));
         magk::tile_meta(ctx->tile_rdeg.as<int32_t>(), ctx->tile_rdeg.as<int32_t>() + T, ctx->tile_off.as<int64_t>(),
                         ctx->tile_hoff.as<int32_t>(), T,
@@ -1293,7 +1295,24 @@ int cg_phase_persist(mag_ctx *ctx)
         HIPCHK(hipMemsetAsync(ctx->pstamps.p, 0, 8 * (size_t)magk::persist_stamp_words() * (size_t)(grid + 1), s));
         P.stamps = ctx->pstamps.as<unsigned long long>();
     }
-    magk::persist_launch(P, ctx->B, grid + P.comm_wg, magk::persist_threads(), s);
+    // Which instantiation: edge blocks in registers when every row of the mesh is one short fan (k_ring16 left the answer
+    // behind tile_rdeg's two arrays), the triangle walk with cached weights otherwise.  One 4-byte read per solve.
+    bool edge_blocks = false;
+    if (!mg && !getenv("MAG_TUNE_PERSIST_TRIANGLES")) {
+        int32_t not_plain = 1;
+        HIPCHK(hipMemcpyAsync(&not_plain, ctx->tile_rdeg.as<int32_t>() + 2 * (size_t)ctx->T, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        edge_blocks = not_plain == 0;
+    }
+    ctx->edge_blocks = edge_blocks;
+    if (edge_blocks) { // the nodes' blocks, once per solve (18 doubles per node of the padded order, value-major)
+        const int64_t npad = (int64_t)ctx->T * ctx->B;
+        HIPCHK(ctx->kblocks.reserve(8 * (size_t)(3 * magk::persist_block_entries()) * (size_t)npad));
+        P.kblocks = ctx->kblocks.as<double>();
+        P.kb_stride = npad;
+        magk::edge_blocks_build(P, ctx->B, ctx->kblocks.as<double>(), s);
+    }
+    magk::persist_launch(P, ctx->B, grid + P.comm_wg, magk::persist_threads(), edge_blocks, s);
     if (stamps) {
         std::vector<unsigned long long> h((size_t)magk::persist_stamp_words() * (size_t)grid);
         HIPCHK(hipMemcpyAsync(h.data(), ctx->pstamps.p, 8 * h.size(), hipMemcpyDeviceToHost, s));
@@ -1951,6 +1970,7 @@ int mag_run(mag_ctx *ctx)
     st.n_free = ctx->nf;
     ctx->have_run = true;
     st.persist_timeout = ctx->persist_timed_out ? 1 : 0;
+    st.edge_blocks = (ctx->cg_kernel == 2 && ctx->edge_blocks) ? 1 : 0;
     st.exchange_timeout = ctx->exchange_timed_out ? 1 : 0;
     if (st.breakdown)
         return fail(ctx, MAG_ERR_NOT_CONVERGED, "Conjugate Gradient error: non-finite residual after %lld iterations",

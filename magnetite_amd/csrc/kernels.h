@@ -281,7 +281,7 @@ struct FusedParams {
     const float4 *halo_minv;
 };
 // rewrites the tile-local table of fill_ell16 into ring form in place (symbolic.hip, k_ring16)
-void ring16(const int32_t *tile_deg, const int64_t *tile_off, int32_t B, int32_t T, uint32_t *ell, int32_t *tile_rdeg,
+void ring16(const int32_t *tile_deg, const int64_t *tile_off, int32_t B, int32_t T, uint32_t *ell, int32_t *tile_rdeg, int32_t block_entries,
             hipStream_t s);
 void tile_meta(const int32_t *tile_deg, const int32_t *tile_ent, const int64_t *tile_off, const int32_t *tile_hoff,
                int32_t T, TileMeta *meta, hipStream_t s);
@@ -343,6 +343,10 @@ struct PersistParams {
     const uint8_t *iface_readers; // n_iface: bit r set when rank r reads the interface node of that slot
     unsigned long long *grec;    // device: 2 * 8 granules, the grid-wide sums republished by workgroup 0
     unsigned long long *stamps;  // diagnostic build (-DMAG_PERSIST_STAMPS) only: per workgroup, phase times in 10 ns ticks
+    // edge-block instantiation: the nodes' symmetric 2 x 2 blocks, value c of node i at kblocks[c * kb_stride + i]
+    // (persist.hip, k_edge_blocks: once per solve, before the launch)
+    const double *kblocks;
+    int64_t kb_stride;
 };
 // multi-GPU, streaming kernels: the per-iteration exchange [dot partials | interface q] through the ranks' device
 // inboxes instead of an all-reduce, in place on `buf` (persist.hip, k_stream_exchange)
@@ -355,7 +359,12 @@ void stream_exchange_launch(double *buf, int32_t g_all, int32_t n_iface, int32_t
 int persist_threads(); // workgroup shape of the on-chip kernel: 512 (x 4 nodes per lane) or 768 (x 3); MAG_TUNE_PERSIST_THREADS
 int persist_tiles_per_wg(int32_t B, int threads); // tiles one workgroup keeps on chip (0: tile size not supported)
 size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh, int threads);
-void persist_launch(const PersistParams &P, int32_t B, int32_t grid, int threads, hipStream_t s); // MG kernel when nranks > 1
+// MG kernel when nranks > 1; edge_blocks: every row qualifies for the edge-block instantiation (ring16's flag)
+void persist_launch(const PersistParams &P, int32_t B, int32_t grid, int threads, bool edge_blocks, hipStream_t s);
+int persist_block_entries(); // block entries per node of that instantiation
+// ... and its blocks: 3 * persist_block_entries() doubles per node of the T * B padded nodes, into P.kblocks (host sets
+// kblocks / kb_stride before the call)
+void edge_blocks_build(const PersistParams &P, int32_t B, double *kblocks, hipStream_t s);
 int persist_stamp_words();   // words per workgroup in PersistParams::stamps
 bool persist_stamps_built(); // the library was compiled with -DMAG_PERSIST_STAMPS
 void mark_published(const int32_t *halo_g, int64_t halo_total, uint8_t *maskP, hipStream_t s);

@@ -56,6 +56,18 @@ __device__ inline void put_granules(unsigned long long *g, unsigned epoch, doubl
                  : "memory");
 }
 
+// The same store addressed as SCALAR base + 32-bit byte offset per lane: the hot loop keeps no 64-bit address per node.
+__device__ inline void put_granules_at(const unsigned long long *base, uint32_t byte_off, unsigned epoch, double2 v)
+{
+    unsigned w[4];
+    __builtin_memcpy(w, &v, 16);
+    const u32x4 a = {w[0], epoch, w[1], epoch}, b = {w[2], epoch, w[3], epoch};
+    asm volatile("global_store_dwordx4 %0, %1, %3 sc1\n\tglobal_store_dwordx4 %0, %2, %3 offset:16 sc1\n\ts_nop 1"
+                 :
+                 : "v"(byte_off), "v"(a), "v"(b), "s"(base)
+                 : "memory");
+}
+
 // Four granules (32 bytes) by two 16-byte sc1 loads: each 8-byte granule lies whole inside one store and validates
 // itself, so it does not matter that the group is not read atomically.  `base` must be wave-uniform (it becomes the
 // buffer resource), the granule group is addressed by the per-lane byte offset.
@@ -596,6 +608,29 @@ constexpr bool kPersistDeferX = MAG_PERSIST_DEFER_X != 0; // x += alpha p in the
 // triangle weights c0 / (2A) kept in registers per node (cg_device.h, ring_walk_cached); 0: recomputed every iteration.
 // The multi-GPU instantiation has no registers to spare for them (237 VGPRs without).
 constexpr int kPersistWeights = MAG_PERSIST_WEIGHTS;
+#ifndef MAG_PERSIST_EDGE_BLOCKS
+#define MAG_PERSIST_EDGE_BLOCKS 1
+#endif
+constexpr bool kPersistEdgeBlocks = MAG_PERSIST_EDGE_BLOCKS != 0; // edge blocks in registers instead of triangle weights
+#ifndef MAG_PERSIST_NB
+#define MAG_PERSIST_NB 6
+#endif
+#ifndef MAG_PERSIST_SADDR
+#define MAG_PERSIST_SADDR 1
+#endif
+#ifndef MAG_PERSIST_ENT_SCALAR
+#define MAG_PERSIST_ENT_SCALAR 1
+#endif
+#ifndef MAG_PERSIST_EB_PACK
+#define MAG_PERSIST_EB_PACK 1
+#endif
+#ifndef MAG_PERSIST_EB_ALL
+#define MAG_PERSIST_EB_ALL 1
+#endif
+#ifndef MAG_PERSIST_EB_FENCE
+#define MAG_PERSIST_EB_FENCE 1
+#endif
+constexpr int kPersistBlockEntries = MAG_PERSIST_NB; // block entries per node: a closed fan of valence 6 is exactly six blocks
 constexpr int kPersistNh = 2;   // halo entries per thread: a workgroup's tiles may carry 2 * THREADS halo nodes in all
 constexpr int persist_npt(int threads) { return threads == 768 ? 3 : 4; } // nodes per lane
 
@@ -619,7 +654,23 @@ constexpr int persist_npt(int threads) { return threads == 768 ? 3 : 4; } // nod
 [[maybe_unused]] constexpr int kStampFrom = 200, kStampTo = 1200;
 constexpr int kStampPhases = 8;
 
-template <int B, bool MG, int THREADS>
+// the per-slot flag bytes of a lane's nodes in ONE register (the on-chip kernel has none to spare)
+template <int N>
+struct PackedFlags {
+    static_assert(N <= 4, "one byte per node slot");
+    uint32_t v = 0;
+    __device__ uint32_t operator[](int s) const { return (v >> (8 * s)) & 0xffu; }
+    __device__ void set(int s, uint32_t f) { v = (v & ~(0xffu << (8 * s))) | ((f & 0xffu) << (8 * s)); }
+};
+
+// a value every lane holds identically, moved to scalar registers
+__device__ inline double uniform_f64(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+template <int B, bool MG, int THREADS, bool EB>
 __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
 {
     constexpr int kPersistThreads = THREADS;
@@ -646,9 +697,12 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
     }
     constexpr int NH = kPersistNh; // halo entries per thread: the workgroup's halo nodes are dealt out over ALL threads
     const unsigned tag0 = (MG ? P.tag_base : 0u) + 1u; // tag of epoch e: tag0 + e - 1
-    int32_t node[NPT], deg[NPT], ent[NPT], oslot[NPT];
+    int32_t deg[NPT], ent[NPT], oslot[NPT];
+    // global (Hilbert) id of slot s's node: the workgroup's tiles are consecutive
+    const int32_t node_base = __builtin_amdgcn_readfirstlane(((MG ? P.t0 : 0) + (int32_t)blockIdx.x * P.tiles_per_wg) * B);
+    auto node_of = [&](int s) { return node_base + s * THREADS + tid; };
     int32_t hg[NH], hloc[NH]; // global id (-1: none) and LDS position (tile * tile_words-relative) of a halo entry
-    uint32_t flags[NPT]; // bit 0/1 prescribed ux/uy, 2 published, 3 live tile, 4 valid node
+    PackedFlags<NPT> flags; // per node slot: bit 0/1 prescribed ux/uy, 2 published, 3 live tile, 4 valid node, 5 fan closed in the blocks
     uint32_t w[NPT][kPersistRegs];
     int64_t ell_off[NPT];
     double2 r[NPT], q[NPT];
@@ -659,11 +713,10 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         const int l = t_loc(s), lt = t_lt(s);
         const int32_t t = (MG ? P.t0 : 0) + blockIdx.x * P.tiles_per_wg + l;
         double2 *xy = t_xy(s), *pim = xy + cap, *hr = pim + cap, *xs = hr + maxh;
-        node[s] = 0;
         oslot[s] = -1;
         deg[s] = 0;
         ent[s] = 0;
-        flags[s] = 3;
+        flags.set(s, 3);
         ell_off[s] = 0;
         r[s] = q[s] = make_double2(0.0, 0.0);
 #pragma unroll
@@ -671,26 +724,32 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         if (!(l < P.tiles_per_wg && t < (MG ? P.t1 : P.T))) continue;
         const TileMeta tm = P.meta[t];
         const int64_t nd = (int64_t)t * B + lt;
-        node[s] = (int32_t)nd;
-        flags[s] = 8;
+        flags.set(s, 8);
         if (nd < P.N) {
             const double2 b = P.bP[nd];
-            r[s] = make_double2(-b.x, -b.y);
-            xy[lt] = P.xyP[nd];
+            if (EB) xy[lt] = make_double2(-b.x, -b.y); // r lives where the triangle walk keeps the coordinates
+            else {
+                r[s] = make_double2(-b.x, -b.y);
+                xy[lt] = P.xyP[nd];
+            }
             const uint32_t mk = P.maskP[nd];
-            flags[s] |= 16u | (mk & 7u);
+            flags.set(s, flags[s] | 16u | (mk & 7u));
             // bit 3 of the mask (k_mark_external): read through memory by a tile of ANOTHER workgroup, or by a sibling tile
             // that keeps its halo copies; a node only its siblings read through their LDS slots publishes nothing
-            if (kPersistSiblings && !MG && !(mk & 8u)) flags[s] &= ~4u;
+            if (kPersistSiblings && !MG && !(mk & 8u)) flags.set(s, flags[s] & ~4u);
             acc[0] += b.x * b.x + b.y * b.y;
         } else {
             xy[lt] = make_double2(0.0, 0.0);
-            flags[s] |= 3;
+            flags.set(s, flags[s] | 3u);
         }
         pim[lt] = make_double2(0.0, 0.0);
         xs[lt] = make_double2(0.0, 0.0);
         deg[s] = tm.deg;
+#if MAG_PERSIST_ENT_SCALAR
+        ent[s] = __builtin_amdgcn_readfirstlane(tm.ent); // one tile per wave and slot
+#else
         ent[s] = tm.ent;
+#endif
         ell_off[s] = tm.ell_off + lt;
 #pragma unroll
         for (int k = 0; k < kPersistRegs; ++k)
@@ -722,6 +781,15 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             for (int k = 0; k < kPersistRegs; ++k)
                 if (k < deg[s]) w[s][k] = remap(w[s][k] & 0xffffu) | (remap(w[s][k] >> 16) << 16);
         }
+        if (EB) {
+            // the fan closes inside the blocks when entry NB is entry 0's node again (k_edge_blocks folded that triangle in);
+            // entries the tile's rows do not reach repeat the last one, so the walk gathers all NB without a test
+            constexpr int NBk = kPersistBlockEntries;
+            static_assert(NBk + 1 <= 2 * kPersistRegs, "entry NB is looked at in the registers");
+            const uint32_t e0 = w[s][0] & 0xffffu, eN = (NBk & 1) ? (w[s][NBk >> 1] >> 16) : (w[s][NBk >> 1] & 0xffffu);
+            if (tm.ent > NBk && !(eN & 0x8000u) && (eN & 0x7fffu) == (e0 & 0x7fffu)) flags.set(s, flags[s] | 32u);
+            ring_pad_entries<kPersistRegs, NBk, 0x7fffu>(w[s], tm.ent);
+        }
         if ((flags[s] & 20) == 20) put_granules(P.qg + 4 * nd, tag0, make_double2(0.0, 0.0)); // q_{-1} = 0, parity 0
         if (MG && (flags[s] & 16)) {
             oslot[s] = P.own_qslot[nd];
@@ -749,7 +817,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
                         }
                     }
                     hloc[e] = l * tile_words + rem;
-                    xy[B + rem] = P.halo_xy[tm.hoff + rem];
+                    if (!EB) xy[B + rem] = P.halo_xy[tm.hoff + rem];
                     const double2 hb = P.bP[hg[e]];
                     xy[2 * cap + rem] = make_double2(-hb.x, -hb.y);      // halo r
                     xy[cap + B + rem] = make_double2(0.0, 0.0);        // halo p: its slot in the p image
@@ -783,19 +851,39 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
 #endif
     constexpr int kW = MG ? MAG_PERSIST_WEIGHTS_MG : kPersistWeights;
     constexpr int NCW = kW > 0 ? kW : 1;
-    constexpr bool CACHED = kW > 0;
-    double wgt[NPT][NCW];
-    if (CACHED) {
+    // Edge blocks (EB instantiation; cg_device.h, ring_blocks): every node's triangles folded into NB symmetric 2 x 2 blocks,
+    // once per solve; a ring step is then one gather of p and six fp64 operations, and the coordinates are not read again.
+    // Only for meshes whose rows are ALL one fan of at most NB entries, or NB + 1 with the last one closing onto the first
+    // (k_ring16 says so: closed fans of valence <= NB, open ones of <= NB - 1 triangles -- every structured mesh); the host
+    // launches the triangle-walk instantiation for any other mesh.
+    constexpr int NB = kPersistBlockEntries;
+    constexpr bool BLOCKS = EB;
+    static_assert(!(EB && MG), "the edge-block instantiation is single-GPU");
+    constexpr bool CACHED = !BLOCKS && kW > 0;
+    constexpr int NKB = BLOCKS ? 3 * NB : NCW;
+    double wgt[NPT][NKB];
+    const double kappa = uniform_f64(0.5 * (h - nu) * c0);
+    if (BLOCKS) { // computed by k_edge_blocks before the launch: loads, no coordinates on the chip at all
+#pragma unroll
+        for (int s = 0; s < NPT; ++s) {
+            const bool live = (flags[s] & 24) == 24;
+#pragma unroll
+            for (int c = 0; c < NKB; ++c) wgt[s][c] = live ? P.kblocks[(int64_t)c * P.kb_stride + node_of(s)] : 0.0;
+        }
+    } else if (CACHED) {
 #pragma unroll
         for (int s = 0; s < NPT; ++s) {
 #pragma unroll
-            for (int c = 0; c < NCW; ++c) wgt[s][c] = 0.0;
+            for (int c = 0; c < NKB; ++c) wgt[s][c] = 0.0;
             if (!(flags[s] & 8)) continue;
             const double2 *xy = t_xy(s);
             const int32_t nent = __builtin_amdgcn_readfirstlane(ent[s]);
-            if (nent > 0) ring_weights<kPersistRegs, NCW, 0x7fffu>(w[s], nent, xy - 3 * tile_words, xy[t_lt(s)], c0, wgt[s]);
+            if (nent > 0)
+                ring_weights<kPersistRegs, NCW, 0x7fffu>(w[s], nent, xy - 3 * tile_words, xy[t_lt(s)], c0,
+                                                         *reinterpret_cast<double(*)[NCW]>(&wgt[s][0]));
         }
     }
+    constexpr bool RL = EB; // r in LDS (in the coordinates' place) instead of registers
     double target = P.tol, bb = 0.0;
     long long j = 0;
     int verdict = 0; // 1 converged, 2 iteration cap, 3 non-finite
@@ -808,8 +896,12 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         ((long long *)s_chunk)[1] = 0;
     }
 #ifdef MAG_PERSIST_STAMPS
-    unsigned long long stamp_sum[kStampPhases] = {}, stamp_last = 0;
-    unsigned long long stamp_iters = 0;
+    // the stamping lane's accumulators live in LDS (the spare words of s_chunk): the edge-block instantiation has no registers
+    // for them, and a spilled register in the loop would be measured along with the phases
+    unsigned long long *stamp_sum = (unsigned long long *)(s_chunk + 16); // [kStampPhases], then `last`, then the count
+    unsigned long long &stamp_last = stamp_sum[kStampPhases], &stamp_iters = stamp_sum[kStampPhases + 1];
+    if (tid == MAG_PERSIST_STAMP_TID)
+        for (int k = 0; k < kStampPhases + 2; ++k) stamp_sum[k] = 0;
 #endif
     for (;;) {
 #ifdef MAG_PERSIST_STAMPS
@@ -819,13 +911,13 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             ++stamp_iters;
         }
 #endif
-        const double S0 = s_S[0], S1 = s_S[1], S2 = s_S[2], S3 = s_S[3];
+        const double S0 = uniform_f64(s_S[0]), S1 = uniform_f64(s_S[1]), S2 = uniform_f64(s_S[2]), S3 = uniform_f64(s_S[3]);
         if (j == 0) {
             bb = S0;
-            target = P.stop_mode == 2 ? P.tol * sqrt(bb) : P.tol;
+            target = uniform_f64(P.stop_mode == 2 ? P.tol * sqrt(bb) : P.tol);
         }
         const double rr = S0;
-        cost = P.stop_mode == 1 ? fabs(rr) : sqrt(rr);
+        cost = uniform_f64(P.stop_mode == 1 ? fabs(rr) : sqrt(rr));
         const long long it_done = j - 1;
         if (reporter && it_done >= 1 && it_done - 1 < P.hist_len) P.hist[it_done - 1] = cost;
         if (j == 0 && bb == 0.0) {
@@ -841,8 +933,8 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         else if (!(fabs(rr) <= 1.79769313486231570e308)) verdict = 3;
         else if (it_done >= P.max_iter) verdict = 2;
         if (verdict) break;
-        const double alpha = rr / S1;
-        const double beta = (rr + 2.0 * alpha * S2 + alpha * alpha * S3) / rr;
+        const double alpha = uniform_f64(rr / S1);
+        const double beta = uniform_f64((rr + 2.0 * alpha * S2 + alpha * alpha * S3) / rr);
 
         // x += alpha p is the one update nothing in the iteration waits for.  It is done in the idle time before the first
         // sweep of the exchange, from what is on the chip by then: alpha p_{j-1} = (alpha / beta) (p_j + r_j) (p_j = -r_j +
@@ -863,10 +955,13 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
                 xo.y += alpha * po.y;
                 xs[lt] = xo;
             }
-            r[s].x += alpha * q[s].x;
-            r[s].y += alpha * q[s].y;
-            pn.x = -r[s].x + beta * po.x;
-            pn.y = -r[s].y + beta * po.y;
+            double2 rv = RL ? xy[lt] : r[s];
+            rv.x += alpha * q[s].x;
+            rv.y += alpha * q[s].y;
+            if (RL) xy[lt] = rv;
+            else r[s] = rv;
+            pn.x = -rv.x + beta * po.x;
+            pn.y = -rv.y + beta * po.y;
             pim[lt] = pn;
         }
 #pragma unroll
@@ -888,6 +983,12 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         // ---- q = M K M p on the owned nodes, dot partials, publication
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = 0.0;
+        if (EB && MAG_PERSIST_EB_PACK) { // the ring words stay packed: unpacked once and for all (loop-invariant) they would take a register per entry
+#pragma unroll
+            for (int s = 0; s < NPT; ++s)
+#pragma unroll
+                for (int k = 0; k < (kPersistBlockEntries + 1) / 2; ++k) asm volatile("" : "+v"(w[s][k]));
+        }
 #pragma unroll
         for (int s = 0; s < NPT; ++s) {
 #if MAG_PERSIST_PRIO == 3
@@ -908,9 +1009,16 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
                 const int32_t nent = __builtin_amdgcn_readfirstlane(ent[s]); // one tile per wave: a scalar
                 if (nent > 0) { // entries are biased slots relative to this tile (see the remap at the top)
                     const uint32_t toff = (uint32_t)(3 * tile_words);
-                    if (CACHED)
+                    if (BLOCKS)
+                        ring_walk_blocks<kPersistRegs, NB, 0x7fffu, MAG_PERSIST_EB_ALL != 0>(w[s], P.ell16 + ell_off[s], B, nent, xy - 3 * tile_words,
+                                                                    pim - 3 * tile_words, ca, pa, c0, nu, h, kappa,
+                                                                    (flags[s] & 32u) != 0, false,
+                                                                    *reinterpret_cast<const double(*)[3 * NB]>(&wgt[s][0]),
+                                                                    fx, fy, toff);
+                    else if (CACHED)
                         ring_walk_cached<kPersistRegs, NCW, 0x7fffu>(w[s], P.ell16 + ell_off[s], B, nent, xy - 3 * tile_words, pim - 3 * tile_words,
-                                                                     ca, pa, c0, nu, h, wgt[s], fx, fy, toff);
+                                                                     ca, pa, c0, nu, h, *reinterpret_cast<const double(*)[NCW]>(&wgt[s][0]),
+                                                                     fx, fy, toff);
                     else
                         ring_walk_uniform<kPersistRegs, kPersistBlock, kPersistBlock2, 0x7fffu>(
                             w[s], P.ell16 + ell_off[s], B, nent, xy - 3 * tile_words, pim - 3 * tile_words, ca, pa, c0, nu, h, fx, fy,
@@ -920,13 +1028,24 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             if ((flags[s] & 1) || !(flags[s] & 16)) fx = 0.0;
             if ((flags[s] & 2) || !(flags[s] & 16)) fy = 0.0;
             q[s] = make_double2(fx, fy);
-            if ((flags[s] & 20) == 20) put_granules(P.qg + 4 * ((int64_t)(par ^ 1) * P.N + node[s]), epoch + 1, q[s]);
+#if MAG_PERSIST_SADDR
+            if ((flags[s] & 20) == 20) // (2 x 32 N bytes of granules: below 4 GB for every mesh the chip can hold)
+                put_granules_at(P.qg, 32u * ((uint32_t)(par ^ 1) * (uint32_t)P.N + (uint32_t)node_of(s)), epoch + 1, q[s]);
+#else
+            if ((flags[s] & 20) == 20) put_granules(P.qg + 4 * ((int64_t)(par ^ 1) * P.N + node_of(s)), epoch + 1, q[s]);
+#endif
             if (MG && oslot[s] >= 0)
                 publish_q(P, par ^ 1, oslot[s], epoch + 1, q[s]);
-            acc[0] += r[s].x * r[s].x + r[s].y * r[s].y;
+            const double2 rv = RL ? xy[lt] : r[s];
+            acc[0] += rv.x * rv.x + rv.y * rv.y;
             acc[1] += pa.x * fx + pa.y * fy;
-            acc[2] += r[s].x * fx + r[s].y * fy;
+            acc[2] += rv.x * fx + rv.y * fy;
             acc[3] += fx * fx + fy * fy;
+#if MAG_PERSIST_EB_FENCE
+            // the edge-block instantiation has no register to spare: keep the scheduler from starting the next slot's
+            // gathers inside this one (one spilled register in the loop costs a memory round trip per iteration)
+            if (EB) __builtin_amdgcn_sched_barrier(0);
+#endif
         }
 #if MAG_PERSIST_PRIO
         __builtin_amdgcn_s_setprio(0);
@@ -940,16 +1059,16 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             put_granules(P.recg + 4 * (2 * ((int64_t)par * cgrid + blockIdx.x) + tid), epoch,
                          tid == 0 ? make_double2(acc[0], acc[1]) : make_double2(acc[2], acc[3]));
         if (kPersistDeferX && !xnow) { // the deferred x += alpha p_{j-1}, in the shadow of the exchange's first wait
-            const double ab = alpha / beta;
+            const double ab = uniform_f64(alpha / beta);
 #pragma unroll
             for (int s = 0; s < NPT; ++s) {
                 if (!(flags[s] & 8)) continue;
                 const int lt = t_lt(s);
                 double2 *xy = t_xy(s), *pim = xy + cap, *xs = pim + cap + maxh;
-                const double2 pj = pim[lt];
+                const double2 pj = pim[lt], rv = RL ? xy[lt] : r[s];
                 double2 xo = xs[lt];
-                xo.x += ab * (pj.x + r[s].x);
-                xo.y += ab * (pj.y + r[s].y);
+                xo.x += ab * (pj.x + rv.x);
+                xo.y += ab * (pj.y + rv.y);
                 xs[lt] = xo;
             }
         }
@@ -981,7 +1100,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
     // x of iterate j-1 is in LDS; the verdict is the same in every workgroup
 #pragma unroll
     for (int s = 0; s < NPT; ++s)
-        if ((flags[s] & 24) == 24) P.x[node[s]] = (t_xy(s) + 2 * cap + maxh)[t_lt(s)];
+        if ((flags[s] & 24) == 24) P.x[node_of(s)] = (t_xy(s) + 2 * cap + maxh)[t_lt(s)];
     if (blockIdx.x == 0 && tid == 0) {
         FusedState *st = P.st;
         st->bb = bb;
@@ -1176,26 +1295,78 @@ size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh, int threads)
 }
 
 template <int THREADS>
-static void persist_launch_t(const PersistParams &P, int32_t B, int32_t grid, size_t lds, hipStream_t s)
+static void persist_launch_t(const PersistParams &P, int32_t B, int32_t grid, size_t lds, bool edge_blocks, hipStream_t s)
 {
     if (P.nranks > 1) {
         if (B == 256)
-            k_cg_persist<256, true, THREADS><<<grid, THREADS, lds, s>>>(P);
+            k_cg_persist<256, true, THREADS, false><<<grid, THREADS, lds, s>>>(P);
         else
-            k_cg_persist<512, true, THREADS><<<grid, THREADS, lds, s>>>(P);
+            k_cg_persist<512, true, THREADS, false><<<grid, THREADS, lds, s>>>(P);
+    } else if (edge_blocks) {
+        if (B == 256)
+            k_cg_persist<256, false, THREADS, true><<<grid, THREADS, lds, s>>>(P);
+        else
+            k_cg_persist<512, false, THREADS, true><<<grid, THREADS, lds, s>>>(P);
     } else if (B == 256)
-        k_cg_persist<256, false, THREADS><<<grid, THREADS, lds, s>>>(P);
+        k_cg_persist<256, false, THREADS, false><<<grid, THREADS, lds, s>>>(P);
     else
-        k_cg_persist<512, false, THREADS><<<grid, THREADS, lds, s>>>(P);
+        k_cg_persist<512, false, THREADS, false><<<grid, THREADS, lds, s>>>(P);
 }
 
-void persist_launch(const PersistParams &P, int32_t B, int32_t grid, int threads, hipStream_t s)
+// edge_blocks: every row of the mesh qualifies for the edge-block instantiation (ring16's flag)
+void persist_launch(const PersistParams &P, int32_t B, int32_t grid, int threads, bool edge_blocks, hipStream_t s)
 {
     const size_t lds = persist_lds_bytes(B, P.cap, P.maxh, threads);
+    edge_blocks = edge_blocks && kPersistEdgeBlocks && P.nranks == 1;
 #ifdef MAG_PERSIST_768
-    if (threads == 768) return persist_launch_t<768>(P, B, grid, lds, s);
+    if (threads == 768) return persist_launch_t<768>(P, B, grid, lds, false, s);
 #endif
-    persist_launch_t<512>(P, B, grid, lds, s);
+    persist_launch_t<512>(P, B, grid, lds, edge_blocks, s);
+}
+
+int persist_block_entries() { return kPersistBlockEntries; }
+
+// The edge blocks of every node (cg_device.h, ring_blocks), once per solve: one thread per node of the padded Hilbert order
+// reads its ring words (tile-local ids) and the coordinates of its neighbours from the tile tables in memory -- owned nodes
+// from xyP, halo nodes from the tile's contiguous halo copy -- and writes the 3 NB numbers, value-major (the on-chip kernel's
+// loads are coalesced).  Only launched for meshes k_ring16 found to qualify (every row one fan of at most NB entries, or
+// NB + 1 closing onto the first).
+template <int B>
+__global__ void __launch_bounds__(256) k_edge_blocks(const PersistParams P, double *kbg)
+{
+    constexpr int NB = kPersistBlockEntries, NW = (NB + 2) / 2;
+    const int64_t nd = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int32_t t = (int32_t)(nd / B), lt = (int32_t)(nd % B);
+    if (t >= P.T) return;
+    const TileMeta tm = P.meta[t];
+    double kb[3 * NB];
+#pragma unroll
+    for (int c = 0; c < 3 * NB; ++c) kb[c] = 0.0;
+    if (nd < P.N && tm.ent > 0) {
+        uint32_t w[NW];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) w[k] = k < tm.deg ? P.ell16[tm.ell_off + lt + (int64_t)k * B] : 0xffffffffu;
+        auto xy_of = [&](uint32_t lid) -> double2 {
+            if (lid < (uint32_t)B) {
+                const int64_t g = (int64_t)t * B + lid;
+                return g < P.N ? P.xyP[g] : make_double2(0.0, 0.0);
+            }
+            return P.halo_xy[tm.hoff + (int32_t)(lid - B)];
+        };
+        ring_blocks<NW, NB, 0xfffu>(w, tm.ent < 2 * NW ? tm.ent : 2 * NW, xy_of, P.xyP[nd], P.c0, P.nu, P.h, kb);
+    }
+#pragma unroll
+    for (int c = 0; c < 3 * NB; ++c) kbg[(int64_t)c * P.kb_stride + nd] = kb[c];
+}
+
+void edge_blocks_build(const PersistParams &P, int32_t B, double *kblocks, hipStream_t s)
+{
+    const int64_t npad = (int64_t)P.T * B;
+    const unsigned blocks = (unsigned)((npad + 255) / 256);
+    if (B == 256)
+        k_edge_blocks<256><<<blocks, 256, 0, s>>>(P, kblocks);
+    else
+        k_edge_blocks<512><<<blocks, 256, 0, s>>>(P, kblocks);
 }
 
 int persist_stamp_words() { return kStampPhases + 1; }

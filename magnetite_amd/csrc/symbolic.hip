@@ -454,12 +454,17 @@ void fill_ell16(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn
 constexpr int kRingMaxDeg = 32;
 
 __global__ void __launch_bounds__(256) k_ring16(const int32_t *tile_deg, const int64_t *tile_off, int32_t B, uint32_t *ell,
-                                                int32_t *tile_rdeg)
+                                                int32_t *tile_rdeg, int32_t nb)
 {
     const int32_t t = blockIdx.x;
     const int32_t td = tile_deg[t];
     uint32_t *dst = ell + tile_off[t];
     int32_t wmax = 0, emax = 0;
+    // Is every row ONE fan of at most nb entries, or nb + 1 with the last entry closing onto the first?  Then the on-chip CG
+    // kernel can fold the mesh into nb edge blocks per node (persist.hip, EB instantiation); one row that is not -- several
+    // fans at a node, a closed fan of valence > nb, an open one of > nb - 1 triangles -- and the whole mesh keeps the
+    // triangle walk.  tile_rdeg[2 T] collects the answer (0: every row qualifies).
+    bool plain = true;
     for (int l = threadIdx.x; l < B; l += 256) {
         uint32_t *row = dst + l; // row[k * B], k < td
         int d = 0;
@@ -471,6 +476,7 @@ __global__ void __launch_bounds__(256) k_ring16(const int32_t *tile_deg, const i
             for (int k = d; k < td; ++k) row[(int64_t)k * B] = pad | (pad << 16);
             words = d;
             emax = 2 * d > emax ? 2 * d : emax;
+            plain = false;
         } else if (d > 0) {
             uint32_t pr[kRingMaxDeg];
             uint16_t out[2 * kRingMaxDeg];
@@ -514,6 +520,8 @@ __global__ void __launch_bounds__(256) k_ring16(const int32_t *tile_deg, const i
             }
             words = (n + 1) / 2;
             emax = n > emax ? n : emax;
+            for (int k = 1; k < n; ++k) plain &= !(out[k] & 0x8000u); // a second fan
+            plain &= n <= nb || (n == nb + 1 && (out[nb] & 0xfffu) == (out[0] & 0xfffu));
             // Padding repeats the last neighbour with the break bit: a walker may treat EVERY entry of the tile's
             // row length as present (no per-entry test), the repeated entry closes no triangle.
             const uint32_t pad = (uint32_t)(out[n - 1] & 0xfffu) | 0x8000u;
@@ -528,13 +536,15 @@ __global__ void __launch_bounds__(256) k_ring16(const int32_t *tile_deg, const i
     }
     if (wmax > 0) atomicMax(&tile_rdeg[t], wmax);
     if (emax > 0) atomicMax(&tile_rdeg[gridDim.x + t], emax); // second half of the array: entries of the longest row
+    if (!plain) atomicOr(&tile_rdeg[2 * gridDim.x], 1);
 }
 
 void ring16(const int32_t *tile_deg, const int64_t *tile_off, int32_t B, int32_t T, uint32_t *ell, int32_t *tile_rdeg,
-            hipStream_t s)
+            int32_t block_entries, hipStream_t s)
 {
-    (void)hipMemsetAsync(tile_rdeg, 0, 2 * 4 * (size_t)T, s); // [0, T): words, [T, 2T): entries of the longest row
-    k_ring16<<<T, 256, 0, s>>>(tile_deg, tile_off, B, ell, tile_rdeg);
+    // [0, T): words, [T, 2T): entries of the longest row, [2T]: some row does not qualify for edge blocks
+    (void)hipMemsetAsync(tile_rdeg, 0, 4 * (2 * (size_t)T + 1), s);
+    k_ring16<<<T, 256, 0, s>>>(tile_deg, tile_off, B, ell, tile_rdeg, block_entries);
 }
 
 // --------------------------------------------------------- CSR pattern ---

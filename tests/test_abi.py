@@ -56,7 +56,7 @@ def test_struct_layouts_match_header(built, tmp_path):
 
 def test_version_defaults_and_constants(built):
     L = _lib.lib()
-    assert L.mag_version() == 3
+    assert L.mag_version() == 4
     o = _lib.Options()
     L.mag_default_options(C.byref(o))
     # solver.rs:17-19

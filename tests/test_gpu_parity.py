@@ -786,7 +786,7 @@ def test_repeated_solves_do_not_grow_device_memory(built):
     assert free_bytes() >= after_first - (1 << 20)
     c.close()
     assert free_bytes() >= base - (8 << 20)
-    assert L.mag_version() == 3
+    assert L.mag_version() == 4
 
 
 def test_timing_hooks_report_plausible_launch_times(built):
@@ -995,3 +995,82 @@ def test_one_context_alternates_between_streaming_and_on_chip_solves(built):
             out = c.solve(p)
             assert c.stats()["cg_kernel"] == fresh[name][1]
             assert np.array_equal(out["u"], fresh[name][0]["u"]) and out["iterations"] == fresh[name][0]["iterations"]
+
+
+def _disc(m, rings):
+    """A disc triangulated ring by ring: ring k carries m * k nodes, so the centre is a CLOSED fan of valence m and every
+    other interior node has valence 6; boundary nodes carry open fans of three or four triangles."""
+    pts, start = [[0.0, 0.0]], [0]
+    for k in range(1, rings + 1):
+        start.append(len(pts))
+        for i in range(m * k):
+            a = 2 * np.pi * i / (m * k)
+            pts.append([k * np.cos(a), k * np.sin(a)])
+    tri = []
+    for k in range(rings):
+        n_in, n_out = max(1, m * k), m * (k + 1)
+        inner = lambda i: start[k] + (i % n_in if k > 0 else 0)
+        outer = lambda i: start[k + 1] + i % n_out
+        for s in range(m):                    # sector s: k inner edges, k + 1 outer edges
+            for j in range(k + 1):
+                o = s * (k + 1) + j
+                i = s * k + j
+                tri.append([inner(min(i, s * k + k) if k else 0), outer(o), outer(o + 1)])
+                if j < k:
+                    tri.append([inner(i), outer(o + 1), inner(i + 1)])
+    return meshgen.Mesh(np.array(pts), np.array(tri, dtype=np.int32), f"disc{m}x{rings}")
+
+
+@pytest.mark.parametrize("case", ["plate", "hole_perturbed", "clockwise", "disc3", "disc4", "disc5", "tile256"])
+def test_on_chip_edge_blocks_match_the_oracle_and_the_triangle_walk(built, case, monkeypatch):
+    """Meshes whose nodes all carry ONE fan of at most six entries run the on-chip kernel's edge-block instantiation
+    (mag_stats.edge_blocks): symmetric 2 x 2 blocks per ring entry built once per solve by k_edge_blocks, antisymmetric
+    parts telescoped per fan.  Closed fans of valence 3, 4, 5 (disc centres; the closing entry sits inside the blocks) and 6
+    (the closing triangle is folded onto entry 0), open fans at the boundary, clockwise elements, perturbed coordinates,
+    both tile sizes.  Checked against the oracle and against the triangle walk of the same library."""
+    monkeypatch.setenv("MAG_TUNE_PERSIST_MIN_K", "1")
+    tile = 512
+    if case == "plate":
+        p = meshgen.config_fixed_left_point_load(meshgen.plate(40))
+    elif case == "hole_perturbed":
+        p = meshgen.config_fixed_left_pull_right(meshgen.shuffle(meshgen.perturb(meshgen.plate_with_holes(120), 0.2, 4), 3))
+    elif case == "clockwise":
+        p = meshgen.config_fixed_left_pull_right(meshgen.clockwise(meshgen.plate_with_holes(64)))
+    elif case == "tile256":
+        p, tile = meshgen.config_fixed_left_pull_right(meshgen.plate_with_holes(96)), 256
+    else:
+        m = int(case[-1])
+        mesh = meshgen.perturb(_disc(m, 24), 0.1, m)
+        rules = [meshgen.BoundaryRule("hold", x_max=-14.0, ux=0.0, uy=0.0), meshgen.BoundaryRule("pull", x_min=14.0, ux=0.01, fy=0.0)]
+        p = meshgen.apply_boundary_rules(mesh, rules)
+    ref = oracle_run(p)
+    with Context(device=0, tile_nodes=tile) as c:
+        out = c.solve(p)
+        st = c.stats()
+        monkeypatch.setenv("MAG_TUNE_PERSIST_TRIANGLES", "1")
+        walk = c.solve(p)
+        st_walk = c.stats()
+        monkeypatch.delenv("MAG_TUNE_PERSIST_TRIANGLES")
+        again = c.solve(p)
+    assert st["cg_kernel"] == 2 and st["edge_blocks"] == 1, case
+    assert st_walk["cg_kernel"] == 2 and st_walk["edge_blocks"] == 0, case
+    assert out["converged"] == 1 and abs(out["iterations"] - ref["iterations"]) <= max(3, ref["iterations"] // 50), case
+    for key in ("u", "f", "stress"):
+        assert rel(out[key], ref[key]) <= TOL_U, (case, key)
+    assert rel(out["u"], walk["u"]) <= 1e-9 and abs(out["iterations"] - walk["iterations"]) <= 2, case
+    assert np.array_equal(out["u"], again["u"])              # bitwise reproducible
+
+
+def test_on_chip_edge_blocks_are_refused_where_a_row_does_not_fit(built, monkeypatch):
+    """One node of valence 12 in an otherwise structured mesh (k_ring16's flag), and a mesh of valence-8 nodes: the whole
+    mesh keeps the triangle walk."""
+    monkeypatch.setenv("MAG_TUNE_PERSIST_MIN_K", "1")
+    for mesh in (_plate_with_a_hub(60), meshgen.perturb(_disc(8, 12), 0.05, 2)):
+        p = meshgen.config_fixed_left_pull_right(mesh) if "hub" in mesh.name else meshgen.apply_boundary_rules(
+            mesh, [meshgen.BoundaryRule("hold", x_max=-7.0, ux=0.0, uy=0.0), meshgen.BoundaryRule("pull", x_min=7.0, ux=0.01, fy=0.0)])
+        ref = oracle_run(p)
+        with Context(device=0, tile_nodes=512) as c:
+            out = c.solve(p)
+            st = c.stats()
+        assert st["cg_kernel"] == 2 and st["edge_blocks"] == 0, mesh.name
+        assert rel(out["u"], ref["u"]) <= TOL_U, mesh.name
