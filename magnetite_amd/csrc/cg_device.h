@@ -354,8 +354,8 @@ __device__ inline void ring_walk_blocks(const uint32_t (&w)[NW], const uint32_t 
     {
         const double2 cp = s_p[entry(0) & IDMASK];
         u0 = make_double2(cp.x - pa.x, cp.y - pa.y);
-        fx += kb[0] * u0.x + kb[1] * u0.y;
-        fy += kb[1] * u0.x + kb[2] * u0.y;
+        fx = fma(kb[1], u0.y, fma(kb[0], u0.x, fx)); // one FMA per term (a sum of two products first costs a third operation)
+        fy = fma(kb[2], u0.y, fma(kb[1], u0.x, fy));
         ul = u0;
     }
 #pragma unroll
@@ -363,8 +363,8 @@ __device__ inline void ring_walk_blocks(const uint32_t (&w)[NW], const uint32_t 
         if (ALL || k < nent) { // nent: a scalar
             const double2 cp = s_p[entry(k) & IDMASK];
             const double2 u = make_double2(cp.x - pa.x, cp.y - pa.y);
-            fx += kb[3 * k] * u.x + kb[3 * k + 1] * u.y;
-            fy += kb[3 * k + 1] * u.x + kb[3 * k + 2] * u.y;
+            fx = fma(kb[3 * k + 1], u.y, fma(kb[3 * k], u.x, fx));
+            fy = fma(kb[3 * k + 2], u.y, fma(kb[3 * k + 1], u.x, fy));
             ul = u;
         }
     const double kap = folded ? 0.0 : kappa; // a fan closed inside the blocks: its antisymmetric parts cancel

@@ -110,7 +110,7 @@ __device__ inline double wave_sum_dpp(double v)
 // thread's halo nodes, swept together until every tag matches; then the records are summed in one fixed two-level
 // order (chunks of eight workgroups, then the chunks) so that all workgroups hold the same bits.  grid <= 256.
 // Returns false when the spin budget runs out (some workgroup is not running): the timeout word is set for the host.
-template <int NH>
+template <int NH, bool EB = false>
 __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigned epoch, const int32_t (&hg)[NH],
                                         double2 (&hq)[NH], double *s_S, double2 *s_rec, double *s_chunk,
                                         unsigned long long *stamp = nullptr)
@@ -140,8 +140,14 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
 #define MAG_PERSIST_SLEEP1 6
 #define MAG_PERSIST_SLEEP2 4
 #endif
-    __builtin_amdgcn_s_sleep(MAG_PERSIST_SLEEP1);
-    if (MAG_PERSIST_SLEEP2 > 0) __builtin_amdgcn_s_sleep(MAG_PERSIST_SLEEP2);
+    // The edge-block instantiation reaches this point ~1.5 us earlier in the iteration; re-swept for it (us per iteration at
+    // 1M / 100k triangles, one box): 4+2 6.79, 6+4 6.69 / 4.50, 8+6 6.63 / 4.37, 10+8 6.66 / 4.32, 12+10 6.73 / 4.39, 14+12 6.81.
+#ifndef MAG_PERSIST_SLEEP1_EB
+#define MAG_PERSIST_SLEEP1_EB 8
+#define MAG_PERSIST_SLEEP2_EB 6
+#endif
+    __builtin_amdgcn_s_sleep(EB ? MAG_PERSIST_SLEEP1_EB : MAG_PERSIST_SLEEP1);
+    if ((EB ? MAG_PERSIST_SLEEP2_EB : MAG_PERSIST_SLEEP2) > 0) __builtin_amdgcn_s_sleep(EB ? MAG_PERSIST_SLEEP2_EB : MAG_PERSIST_SLEEP2);
 #ifdef MAG_PERSIST_STAMPS
     if (stamp) stamp[0] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -263,14 +269,16 @@ __device__ inline bool get_granules_sys(const unsigned long long *base, uint32_t
 }
 
 // q of an interface node this rank owns, into the inbox of every rank that reads it
-__device__ inline void publish_q(const PersistParams &P, int par, int32_t slot, unsigned tag, double2 v)
+// `readers`: P.iface_readers[slot], loaded ONCE per solve by the caller.  Loaded here, the loop below would start with a wait
+// for the memory counter at the top of every round -- and on gfx9 that counter holds the stores as well: every rank's
+// store would wait for the previous one's round trip across xGMI.
+__device__ inline void publish_q(const PersistParams &P, int par, int32_t slot, uint32_t readers, unsigned tag, double2 v)
 {
     const size_t off = 64 + 128 * (size_t)P.nranks + 32 * ((size_t)par * P.n_iface + slot);
     if (P.win_shared) {
         put_granules_sys((unsigned long long *)(P.inbox[0] + off), tag, v);
         return;
     }
-    const uint32_t readers = P.iface_readers[slot];
     for (int r = 0; r < P.nranks; ++r)
         if ((readers >> r) & 1u) put_granules_sys((unsigned long long *)(P.inbox[r] + off), tag, v);
 }
@@ -698,6 +706,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
     constexpr int NH = kPersistNh; // halo entries per thread: the workgroup's halo nodes are dealt out over ALL threads
     const unsigned tag0 = (MG ? P.tag_base : 0u) + 1u; // tag of epoch e: tag0 + e - 1
     int32_t deg[NPT], ent[NPT], oslot[NPT];
+    uint32_t oreaders[NPT]; // multi-GPU: the ranks that read this node's q (bit r), for the nodes with an interface slot
     // global (Hilbert) id of slot s's node: the workgroup's tiles are consecutive
     const int32_t node_base = __builtin_amdgcn_readfirstlane(((MG ? P.t0 : 0) + (int32_t)blockIdx.x * P.tiles_per_wg) * B);
     auto node_of = [&](int s) { return node_base + s * THREADS + tid; };
@@ -714,6 +723,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         const int32_t t = (MG ? P.t0 : 0) + blockIdx.x * P.tiles_per_wg + l;
         double2 *xy = t_xy(s), *pim = xy + cap, *hr = pim + cap, *xs = hr + maxh;
         oslot[s] = -1;
+        oreaders[s] = 0;
         deg[s] = 0;
         ent[s] = 0;
         flags.set(s, 3);
@@ -793,7 +803,11 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         if ((flags[s] & 20) == 20) put_granules(P.qg + 4 * nd, tag0, make_double2(0.0, 0.0)); // q_{-1} = 0, parity 0
         if (MG && (flags[s] & 16)) {
             oslot[s] = P.own_qslot[nd];
-            if (oslot[s] >= 0) publish_q(P, 0, oslot[s], tag0, make_double2(0.0, 0.0));
+            if (oslot[s] >= 0) {
+                if (!P.win_shared) oreaders[s] = P.iface_readers[oslot[s]];
+                asm volatile("" : "+v"(oreaders[s])); // landed: nothing of it is in flight when the stores begin
+                publish_q(P, 0, oslot[s], oreaders[s], tag0, make_double2(0.0, 0.0));
+            }
         }
     }
     // halo entries of the workgroup's tiles, in tile order, dealt out round-robin: thread t takes entries t, t + 512
@@ -840,7 +854,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
                      tid == 0 ? make_double2(acc[0], acc[1]) : make_double2(acc[2], acc[3]));
     double2 hq[NH]; // q of this thread's halo nodes
     if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec)
-           : !persist_exchange<NH>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk))
+           : !persist_exchange<NH, EB>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk))
         return;
 
     const double c0 = P.c0, nu = P.nu, h = P.h;
@@ -870,6 +884,13 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
 #pragma unroll
             for (int c = 0; c < NKB; ++c) wgt[s][c] = live ? P.kblocks[(int64_t)c * P.kb_stride + node_of(s)] : 0.0;
         }
+        // Every load has landed before the loop: a block still "in flight" at the loop's entry makes the compiler wait for
+        // the memory counter inside every node slot's walk -- where that counter also holds the previous slot's granule
+        // stores, i.e. a full store round trip per slot and iteration.
+#pragma unroll
+        for (int s = 0; s < NPT; ++s)
+#pragma unroll
+            for (int c = 0; c < NKB; ++c) asm volatile("" : "+v"(wgt[s][c]));
     } else if (CACHED) {
 #pragma unroll
         for (int s = 0; s < NPT; ++s) {
@@ -1035,7 +1056,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             if ((flags[s] & 20) == 20) put_granules(P.qg + 4 * ((int64_t)(par ^ 1) * P.N + node_of(s)), epoch + 1, q[s]);
 #endif
             if (MG && oslot[s] >= 0)
-                publish_q(P, par ^ 1, oslot[s], epoch + 1, q[s]);
+                publish_q(P, par ^ 1, oslot[s], oreaders[s], epoch + 1, q[s]);
             const double2 rv = RL ? xy[lt] : r[s];
             acc[0] += rv.x * rv.x + rv.y * rv.y;
             acc[1] += pa.x * fx + pa.y * fy;
@@ -1076,7 +1097,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
 #ifdef MAG_PERSIST_STAMPS
         unsigned long long xs_[3] = {0, 0, 0};
         if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec)
-               : !persist_exchange<NH>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk, stamping ? xs_ : nullptr))
+               : !persist_exchange<NH, EB>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk, stamping ? xs_ : nullptr))
             return;
         if (stamping) { // inside the exchange: wait before the first sweep / sweeps until complete / record reduction
             stamp_sum[4] += xs_[0] - stamp_last;
@@ -1086,7 +1107,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         }
 #else
         if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec)
-               : !persist_exchange<NH>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk))
+               : !persist_exchange<NH, EB>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk))
             return;
 #endif
     }
@@ -1160,8 +1181,11 @@ __global__ void __launch_bounds__(256) k_stream_exchange(const StreamExchangePar
     for (int32_t k = blockIdx.x * 256 + tid; k < P.n_iface; k += gridDim.x * 256) {
         const int32_t g = P.iface[k];
         if (g < P.own0 || g >= P.own1) continue;
-        const uint32_t readers = P.iface_readers[k];
-        const double2 v = q[k];
+        uint32_t readers = P.iface_readers[k];
+        double2 v = q[k];
+        // both landed before the first store: a load still in flight at the loop's entry would put a wait for the memory
+        // counter -- which also counts the stores -- at the top of every round: one store round trip across xGMI per reader
+        asm volatile("" : "+v"(readers), "+v"(v.x), "+v"(v.y));
         for (int r = 0; r < R; ++r)
             if (r != P.rank && ((readers >> r) & 1u))
                 put_granules_sys((unsigned long long *)(P.inbox[r] + qoff + 32 * ((size_t)xpar * P.n_iface + k)), xtag, v);
