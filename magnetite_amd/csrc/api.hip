@@ -1298,7 +1298,9 @@ int cg_phase_persist(mag_ctx *ctx)
     // Which instantiation: edge blocks in registers when every row of the mesh is one short fan (k_ring16 left the answer
     // behind tile_rdeg's two arrays), the triangle walk with cached weights otherwise.  One 4-byte read per solve.
     bool edge_blocks = false;
-    if (!mg && !getenv("MAG_TUNE_PERSIST_TRIANGLES")) {
+    // (several ranks: the ordering phase is replicated, so every rank reads the same flag; the multi-GPU edge-block
+    // instantiation is behind MAG_TUNE_PERSIST_MG_BLOCKS until a node has measured it)
+    if ((!mg || getenv("MAG_TUNE_PERSIST_MG_BLOCKS")) && !getenv("MAG_TUNE_PERSIST_TRIANGLES")) {
         int32_t not_plain = 1;
         HIPCHK(hipMemcpyAsync(&not_plain, ctx->tile_rdeg.as<int32_t>() + 2 * (size_t)ctx->T, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));

@@ -269,18 +269,31 @@ __device__ inline bool get_granules_sys(const unsigned long long *base, uint32_t
 }
 
 // q of an interface node this rank owns, into the inbox of every rank that reads it
+// system-scope granules at SCALAR base + 32-bit byte offset (no 64-bit address per node kept across the loop)
+__device__ inline void put_granules_sys_at(const uint8_t *base, uint32_t byte_off, unsigned tag, double2 v)
+{
+    unsigned w[4];
+    __builtin_memcpy(w, &v, 16);
+    const u32x4 a = {w[0], tag, w[1], tag}, b = {w[2], tag, w[3], tag};
+    asm volatile("global_store_dwordx4 %0, %1, %3 sc0 sc1\n\tglobal_store_dwordx4 %0, %2, %3 offset:16 sc0 sc1\n\ts_nop 1"
+                 :
+                 : "v"(byte_off), "v"(a), "v"(b), "s"(base)
+                 : "memory");
+}
+
 // `readers`: P.iface_readers[slot], loaded ONCE per solve by the caller.  Loaded here, the loop below would start with a wait
 // for the memory counter at the top of every round -- and on gfx9 that counter holds the stores as well: every rank's
 // store would wait for the previous one's round trip across xGMI.
 __device__ inline void publish_q(const PersistParams &P, int par, int32_t slot, uint32_t readers, unsigned tag, double2 v)
 {
-    const size_t off = 64 + 128 * (size_t)P.nranks + 32 * ((size_t)par * P.n_iface + slot);
+    // (an inbox is 64 + 128 R + 64 n_iface bytes: far below 4 GB)
+    const uint32_t off = 64u + 128u * (uint32_t)P.nranks + 32u * ((uint32_t)par * (uint32_t)P.n_iface + (uint32_t)slot);
     if (P.win_shared) {
-        put_granules_sys((unsigned long long *)(P.inbox[0] + off), tag, v);
+        put_granules_sys_at(P.inbox[0], off, tag, v);
         return;
     }
     for (int r = 0; r < P.nranks; ++r)
-        if ((readers >> r) & 1u) put_granules_sys((unsigned long long *)(P.inbox[r] + off), tag, v);
+        if ((readers >> r) & 1u) put_granules_sys_at(P.inbox[r], off, tag, v);
 }
 
 // Exchange of the multi-GPU kernel.  Halo q: from this GPU's granules, or from the window when another rank owns the
@@ -629,6 +642,9 @@ constexpr bool kPersistEdgeBlocks = MAG_PERSIST_EDGE_BLOCKS != 0; // edge blocks
 #ifndef MAG_PERSIST_ENT_SCALAR
 #define MAG_PERSIST_ENT_SCALAR 1
 #endif
+#ifndef MAG_PERSIST_PACK_MG
+#define MAG_PERSIST_PACK_MG 1
+#endif
 #ifndef MAG_PERSIST_EB_PACK
 #define MAG_PERSIST_EB_PACK 1
 #endif
@@ -861,7 +877,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
     // iteration-invariant part of the ring walks: the triangles' weights c0 / (2A), once per solve (the exchange above
     // ended with a workgroup barrier: the coordinates are staged)
 #ifndef MAG_PERSIST_WEIGHTS_MG
-#define MAG_PERSIST_WEIGHTS_MG 0
+#define MAG_PERSIST_WEIGHTS_MG 6
 #endif
     constexpr int kW = MG ? MAG_PERSIST_WEIGHTS_MG : kPersistWeights;
     constexpr int NCW = kW > 0 ? kW : 1;
@@ -872,7 +888,6 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
     // launches the triangle-walk instantiation for any other mesh.
     constexpr int NB = kPersistBlockEntries;
     constexpr bool BLOCKS = EB;
-    static_assert(!(EB && MG), "the edge-block instantiation is single-GPU");
     constexpr bool CACHED = !BLOCKS && kW > 0;
     constexpr int NKB = BLOCKS ? 3 * NB : NCW;
     double wgt[NPT][NKB];
@@ -1004,11 +1019,14 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         // ---- q = M K M p on the owned nodes, dot partials, publication
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[c] = 0.0;
-        if (EB && MAG_PERSIST_EB_PACK) { // the ring words stay packed: unpacked once and for all (loop-invariant) they would take a register per entry
+        // the ring words stay packed: unpacked once and for all (loop-invariant) they take a register per entry -- 24 in the
+        // edge-block instantiation, 40 in the others (where MAG_PERSIST_PACK_MG does the same for the multi-GPU instantiation:
+        // the registers go to the cached triangle weights)
+        if ((EB && MAG_PERSIST_EB_PACK) || (MG && !EB && MAG_PERSIST_PACK_MG)) {
 #pragma unroll
             for (int s = 0; s < NPT; ++s)
 #pragma unroll
-                for (int k = 0; k < (kPersistBlockEntries + 1) / 2; ++k) asm volatile("" : "+v"(w[s][k]));
+                for (int k = 0; k < (EB ? (kPersistBlockEntries + 1) / 2 : kPersistRegs); ++k) asm volatile("" : "+v"(w[s][k]));
         }
 #pragma unroll
         for (int s = 0; s < NPT; ++s) {
@@ -1322,7 +1340,12 @@ template <int THREADS>
 static void persist_launch_t(const PersistParams &P, int32_t B, int32_t grid, size_t lds, bool edge_blocks, hipStream_t s)
 {
     if (P.nranks > 1) {
-        if (B == 256)
+        if (edge_blocks) {
+            if (B == 256)
+                k_cg_persist<256, true, THREADS, true><<<grid, THREADS, lds, s>>>(P);
+            else
+                k_cg_persist<512, true, THREADS, true><<<grid, THREADS, lds, s>>>(P);
+        } else if (B == 256)
             k_cg_persist<256, true, THREADS, false><<<grid, THREADS, lds, s>>>(P);
         else
             k_cg_persist<512, true, THREADS, false><<<grid, THREADS, lds, s>>>(P);
@@ -1341,7 +1364,7 @@ static void persist_launch_t(const PersistParams &P, int32_t B, int32_t grid, si
 void persist_launch(const PersistParams &P, int32_t B, int32_t grid, int threads, bool edge_blocks, hipStream_t s)
 {
     const size_t lds = persist_lds_bytes(B, P.cap, P.maxh, threads);
-    edge_blocks = edge_blocks && kPersistEdgeBlocks && P.nranks == 1;
+    edge_blocks = edge_blocks && kPersistEdgeBlocks;
 #ifdef MAG_PERSIST_768
     if (threads == 768) return persist_launch_t<768>(P, B, grid, lds, false, s);
 #endif
