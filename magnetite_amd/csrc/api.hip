@@ -85,6 +85,8 @@ struct mag_ctx {
     DevBuf scratch, small; // rocPRIM temp; small = bbox partials, bbox, err flag
     DevBuf sK0, sK1, sV0, sV1;
     DevBuf perm, iperm, xyP, maskP, deg, inc_off, inc, tile_deg, tile_rdeg, tile_cnt, tile_off, ell, ell_asm, ell_pos;
+    DevBuf bc_touch; // N bytes: rows with a prescribed column (k_pattern_rows; k_mark_bc_rows on the sort-based pattern)
+    bool bc_touch_ready = false;
     DevBuf kblocks; // on-chip CG, edge-block instantiation: the nodes' blocks (k_edge_blocks)
     bool asm_ctile = false; // K is assembled from the CG tiles (k_assemble_fan), ell_asm holds its corner words
     // tile-local numbering for the LDS-halo operator
@@ -491,6 +493,7 @@ int ensure_order(mag_ctx *ctx)
 // ---- symbolic phase 2 + numeric assembly: K in CSR, caller numbering ----
 int csr_symbolic(mag_ctx *ctx)
 {
+    ctx->bc_touch_ready = false;
     const int64_t N = ctx->N, E = ctx->E;
     int64_t n9 = 9 * E;
     hipStream_t s = ctx->stream;
@@ -536,8 +539,11 @@ int csr_symbolic(mag_ctx *ctx)
             ctx->nb = nb;
             HIPCHK(ctx->bcol.reserve(4 * (size_t)nb));
             HIPCHK(ctx->kval.reserve(8 * 4 * (size_t)nb));
+            HIPCHK(ctx->bc_touch.reserve((size_t)N + 16));
             magk::pattern_fill(ctx->inc_off.as<int32_t>(), ctx->inc.as<uint32_t>(), ctx->perm.as<uint32_t>(),
-                               ctx->conn.as<int32_t>(), local, N, ctx->bptr.as<int32_t>(), ctx->bcol.as<int32_t>(), s);
+                               ctx->conn.as<int32_t>(), local, N, ctx->bptr.as<int32_t>(), ctx->bcol.as<int32_t>(),
+                               ctx->uknown.as<uint8_t>(), ctx->bc_touch.as<uint8_t>(), s);
+            ctx->bc_touch_ready = true;
             HIPCHK(hipGetLastError());
             return MAG_OK;
         }
@@ -1863,9 +1869,11 @@ int mag_run(mag_ctx *ctx)
         ctx->have_csr = true;
         HIPCHK(hipEventRecord(ctx->ev[4], s));
         if (ctx->opt.verbose) printf("info: setting up system...\n");
+        HIPCHK(ctx->bc_touch.reserve((size_t)N + 16));
         magk::rhs_from_csr(ctx->bptr.as<int32_t>(), ctx->bcol.as<int32_t>(), ctx->kval.as<double>(),
                            ctx->uknown.as<uint8_t>(), ctx->uin.as<double>(), ctx->fin.as<double>(),
-                           ctx->iperm.as<int32_t>(), N, ctx->bP.as<double>(), s);
+                           ctx->perm.as<uint32_t>(), ctx->bc_touch.as<uint8_t>(), ctx->bc_touch_ready, N,
+                           ctx->bP.as<double>(), s);
     } else {
         HIPCHK(hipEventRecord(ctx->ev[2], s));
         HIPCHK(hipEventRecord(ctx->ev[3], s));

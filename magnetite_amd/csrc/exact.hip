@@ -553,6 +553,28 @@ __device__ inline void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// One 16-byte piece of K.  MAG_ASM_STORE: 0 plain (write-back), 1 non-temporal, 2 write-through (sc1: the bytes go out while
+// the kernel still computes).  Measured in one session, numeric assembly at 1M / 4M triangles: 45.0 / 166.8 us plain,
+// 42.9 / 171.2 non-temporal, 42.8 / 162.4 write-through (scripts/asm_store_ab.py): write-through.
+#ifndef MAG_ASM_STORE
+#define MAG_ASM_STORE 2
+#endif
+__device__ inline void k_store(double *dst, double2 v)
+{
+#if MAG_ASM_STORE == 1
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    v2d t = {v.x, v.y};
+    __builtin_nontemporal_store(t, (v2d *)dst);
+#elif MAG_ASM_STORE == 2
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    u4 t;
+    __builtin_memcpy(&t, &v, 16);
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(t) : "memory");
+#else
+    *(double2 *)dst = v;
+#endif
+}
+
 constexpr int kFanThreads = 256; // 32 nodes x 8 lanes per pass
 constexpr int kFanLanes = 8;     // lanes (triangles, columns) per node
 constexpr int kFanStage = 20;    // 16-byte pieces of staging per node: two rows of at most ten blocks
@@ -717,8 +739,7 @@ __global__ void __launch_bounds__(kFanThreads) k_assemble_fan(const int32_t *bco
             for (int j = 0; j < (NPW + 3) / 4; ++j) {
                 const int node = 4 * j + (wl >> 4), piece = wl & 15;
                 const int2 h = node < NPW ? hdr[node] : make_int2(0, 0);
-                if (piece < 2 * h.y)
-                    *(double2 *)(kval + 4 * (int64_t)h.x + 2 * piece) = wreg[node * kFanStage + piece];
+                if (piece < 2 * h.y) k_store(kval + 4 * (int64_t)h.x + 2 * piece, wreg[node * kFanStage + piece]);
                 longrow |= h.y > 8;
             }
             if (__any(longrow ? 1 : 0)) { // rows of nine or ten blocks (open fans of seven or eight triangles): pieces 16-19
@@ -726,8 +747,7 @@ __global__ void __launch_bounds__(kFanThreads) k_assemble_fan(const int32_t *bco
                 for (int j = 0; j < (NPW + 3) / 4; ++j) {
                     const int node = 4 * j + (wl >> 4), piece = 16 + (wl & 15);
                     const int2 h = node < NPW ? hdr[node] : make_int2(0, 0);
-                    if (piece < 2 * h.y)
-                        *(double2 *)(kval + 4 * (int64_t)h.x + 2 * piece) = wreg[node * kFanStage + piece];
+                    if (piece < 2 * h.y) k_store(kval + 4 * (int64_t)h.x + 2 * piece, wreg[node * kFanStage + piece]);
                 }
             }
             if (!rowfan && cnt > 0 && k == 0 && i >= 0) {
@@ -888,20 +908,46 @@ __device__ inline double rhs_row(const int32_t *bptr, const int32_t *bcol, const
     return s + f_in[r];
 }
 
-__global__ void __launch_bounds__(256) k_rhs_from_csr(const int32_t *bptr, const int32_t *bcol, const double *kval,
-                                                      const uint8_t *u_known, const double *u_in, const double *f_in,
-                                                      const int32_t *iperm, int64_t N, double *bP)
+// Rows with a prescribed column: marked from the PRESCRIBED side.  The pattern is symmetric node by node (solver.rs:304-322:
+// every (node, node) pair of an element, both ways) and every rank keeps the rows of the prescribed nodes, so the columns of
+// a prescribed node's row are exactly the rows that have it as a column -- O(boundary) work instead of a gather of u_known
+// behind every one of the 14 M column entries.
+__global__ void __launch_bounds__(256) k_mark_bc_rows(const int32_t *bptr, const int32_t *bcol, const uint8_t *u_known,
+                                                      int64_t N, uint8_t *touch)
 {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= 2 * N) return;
-    const double v = u_known[r] ? 0.0 : rhs_row(bptr, bcol, kval, u_known, u_in, f_in, r);
-    bP[2 * (int64_t)iperm[r >> 1] + (r & 1)] = v;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    if (!(u_known[2 * i] | u_known[2 * i + 1])) return;
+    for (int32_t k = bptr[i]; k < bptr[i + 1]; ++k) touch[bcol[k]] = 1; // (racing stores of the same value)
 }
 
-void rhs_from_csr(const int32_t *bptr, const int32_t *bcol, const double *kval, const uint8_t *u_known,
-                  const double *u_in, const double *f_in, const int32_t *iperm, int64_t N, double *bP, hipStream_t s)
+// One thread per node of the HILBERT order (b is written in that order: one coalesced 16-byte store per node; the caller-order
+// inputs are gathered -- scattered 8-byte stores through the permutation cost more than the whole row sums).
+__global__ void __launch_bounds__(256) k_rhs_from_csr(const int32_t *bptr, const int32_t *bcol, const double *kval,
+                                                      const uint8_t *u_known, const double *u_in, const double *f_in,
+                                                      const uint32_t *perm, const uint8_t *touch, int64_t N, double2 *bP)
 {
-    k_rhs_from_csr<<<blocks_for(2 * N, 256), 256, 0, s>>>(bptr, bcol, kval, u_known, u_in, f_in, iperm, N, bP);
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= N) return;
+    const int64_t i = perm[g];
+    const bool t = touch[i] != 0;
+    double2 v;
+    // a row without a prescribed column: rhs_row's sum stays at its 0.0, i.e. 0.0 + f (the same bits, -0.0 included)
+    v.x = u_known[2 * i] ? 0.0 : (t ? rhs_row(bptr, bcol, kval, u_known, u_in, f_in, 2 * i) : 0.0 + f_in[2 * i]);
+    v.y = u_known[2 * i + 1] ? 0.0 : (t ? rhs_row(bptr, bcol, kval, u_known, u_in, f_in, 2 * i + 1) : 0.0 + f_in[2 * i + 1]);
+    bP[g] = v;
+}
+
+// touch: N bytes; touch_ready: already filled by the pattern kernel (symbolic.hip, k_pattern_rows), else marked here
+void rhs_from_csr(const int32_t *bptr, const int32_t *bcol, const double *kval, const uint8_t *u_known,
+                  const double *u_in, const double *f_in, const uint32_t *perm, uint8_t *touch, bool touch_ready,
+                  int64_t N, double *bP, hipStream_t s)
+{
+    if (!touch_ready) {
+        (void)hipMemsetAsync(touch, 0, (size_t)N, s);
+        k_mark_bc_rows<<<blocks_for(N, 256), 256, 0, s>>>(bptr, bcol, u_known, N, touch);
+    }
+    k_rhs_from_csr<<<blocks_for(N, 256), 256, 0, s>>>(bptr, bcol, kval, u_known, u_in, f_in, perm, touch, N, (double2 *)bP);
 }
 
 __global__ void __launch_bounds__(256) k_rhs_compact(const int32_t *bptr, const int32_t *bcol, const double *kval,

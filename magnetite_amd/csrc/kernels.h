@@ -56,7 +56,8 @@ void csr_pairs(const int32_t *conn, int64_t E, uint64_t *keys, uint32_t *vals, h
 void pattern_count(const int32_t *inc_off, const uint32_t *inc, const uint32_t *perm, const int32_t *conn,
                    const uint8_t *local, int64_t N, int32_t *rowcnt, int32_t *overflow, hipStream_t s);
 void pattern_fill(const int32_t *inc_off, const uint32_t *inc, const uint32_t *perm, const int32_t *conn,
-                  const uint8_t *local, int64_t N, const int32_t *bptr, int32_t *bcol, hipStream_t s);
+                  const uint8_t *local, int64_t N, const int32_t *bptr, int32_t *bcol, const uint8_t *u_known,
+                  uint8_t *touch, hipStream_t s);
 // multi-GPU: local[i] = 1 for the nodes whose K rows this rank keeps (owned, one ghost layer, prescribed nodes) ...
 void mark_local(const uint32_t *perm, const uint8_t *maskP, int64_t N, int32_t own0, int32_t own1,
                 const int32_t *halo_g, int32_t h0, int32_t h1, uint8_t *local, hipStream_t s);
@@ -109,8 +110,8 @@ bool assemble_ctiles(const int32_t *bcol, const int32_t *bptr, const uint32_t *p
 // solver.rs:365-404,427-432: b[row] = sum_{known cols, ascending} -(K*u) + f  (0 on prescribed rows),
 // written in Hilbert order: bP[2*iperm[node]+a]
 void rhs_from_csr(const int32_t *bptr, const int32_t *bcol, const double *kval, const uint8_t *u_known,
-                  const double *u_in, const double *f_in, const int32_t *iperm, int64_t N, double *bP,
-                  hipStream_t s);
+                  const double *u_in, const double *f_in, const uint32_t *perm, uint8_t *touch, bool touch_ready,
+                  int64_t N, double *bP, hipStream_t s);
 // same, compact numbering (for mag_reduce_system)
 void rhs_compact(const int32_t *bptr, const int32_t *bcol, const double *kval, const uint8_t *u_known,
                  const double *u_in, const double *f_in, const int32_t *fidx, int64_t N, double *b, hipStream_t s);

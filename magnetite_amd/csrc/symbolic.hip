@@ -61,17 +61,24 @@ __global__ void __launch_bounds__(256) k_bbox_partial(const double2 *xy, int64_t
     }
 }
 
-__global__ void k_bbox_final(const double *part, int nblocks, double *bbox4)
+// one wave: lane k takes partials k, k + 64, ... (min and max are exact and order-independent: the same box whatever the
+// order), then the wave tree of the partial kernel.  (A single thread walking the partials took 40 us.)
+__global__ void __launch_bounds__(64) k_bbox_final(const double *part, int nblocks, double *bbox4)
 {
+    double xlo = 1.0e308, ylo = 1.0e308, xhi = -1.0e308, yhi = -1.0e308;
+    for (int k = threadIdx.x; k < nblocks; k += 64) {
+        xlo = fmin(xlo, part[4 * k]);
+        ylo = fmin(ylo, part[4 * k + 1]);
+        xhi = fmax(xhi, part[4 * k + 2]);
+        yhi = fmax(yhi, part[4 * k + 3]);
+    }
+    wave_minmax(xlo, xhi);
+    wave_minmax(ylo, yhi);
     if (threadIdx.x == 0) {
-        double b[4] = {part[0], part[1], part[2], part[3]};
-        for (int k = 1; k < nblocks; ++k) {
-            b[0] = fmin(b[0], part[4 * k]);
-            b[1] = fmin(b[1], part[4 * k + 1]);
-            b[2] = fmax(b[2], part[4 * k + 2]);
-            b[3] = fmax(b[3], part[4 * k + 3]);
-        }
-        for (int k = 0; k < 4; ++k) bbox4[k] = b[k];
+        bbox4[0] = xlo;
+        bbox4[1] = ylo;
+        bbox4[2] = xhi;
+        bbox4[3] = yhi;
     }
 }
 
@@ -577,7 +584,8 @@ constexpr int kRowCap = 16;
 template <bool FILL>
 __global__ void __launch_bounds__(256) k_pattern_rows(const int32_t *inc_off, const uint32_t *inc, const uint32_t *perm,
                                                       const int32_t *conn, const uint8_t *local, int64_t N,
-                                                      const int32_t *bptr, int32_t *out, int32_t *overflow)
+                                                      const int32_t *bptr, int32_t *out, int32_t *overflow,
+                                                      const uint8_t *u_known, uint8_t *touch)
 {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g > N) return;
@@ -588,6 +596,7 @@ __global__ void __launch_bounds__(256) k_pattern_rows(const int32_t *inc_off, co
     const int64_t i = perm[g];
     if (local && !local[i]) {
         if (!FILL) out[i] = 0;
+        if (FILL && touch) touch[i] = 0;
         return;
     }
     int32_t cols[kRowCap];
@@ -635,6 +644,16 @@ __global__ void __launch_bounds__(256) k_pattern_rows(const int32_t *inc_off, co
 #pragma unroll
         for (int k = 0; k < kRowCap; ++k)
             if (k < n) out[p + k] = cols[k];
+        // While the row's columns are in registers: does the row have a PRESCRIBED column?  One 2-byte gather per block
+        // column here instead of four 1-byte gathers per block in the right-hand side's pass over K (exact.hip, rhs_row):
+        // rows without one -- all but the boundary's neighbours -- take b = 0.0 + f there and never look at K.
+        if (touch) {
+            unsigned t = 0;
+#pragma unroll
+            for (int k = 0; k < kRowCap; ++k)
+                if (k < n) t |= ((const uint16_t *)u_known)[cols[k]];
+            touch[i] = t ? 1 : 0;
+        }
     } else {
         out[i] = over ? 0 : n;
         if (over) *overflow = 1;
@@ -645,13 +664,16 @@ void pattern_count(const int32_t *inc_off, const uint32_t *inc, const uint32_t *
                    const uint8_t *local, int64_t N, int32_t *rowcnt, int32_t *overflow, hipStream_t s)
 {
     k_pattern_rows<false><<<blocks_for(N + 1, 256), 256, 0, s>>>(inc_off, inc, perm, conn, local, N, nullptr, rowcnt,
-                                                                overflow);
+                                                                overflow, nullptr, nullptr);
 }
 
+// touch (N bytes, may be null): 1 for the rows with a prescribed column (u_known: 2N bytes, caller numbering)
 void pattern_fill(const int32_t *inc_off, const uint32_t *inc, const uint32_t *perm, const int32_t *conn,
-                  const uint8_t *local, int64_t N, const int32_t *bptr, int32_t *bcol, hipStream_t s)
+                  const uint8_t *local, int64_t N, const int32_t *bptr, int32_t *bcol, const uint8_t *u_known,
+                  uint8_t *touch, hipStream_t s)
 {
-    k_pattern_rows<true><<<blocks_for(N + 1, 256), 256, 0, s>>>(inc_off, inc, perm, conn, local, N, bptr, bcol, nullptr);
+    k_pattern_rows<true><<<blocks_for(N + 1, 256), 256, 0, s>>>(inc_off, inc, perm, conn, local, N, bptr, bcol, nullptr,
+                                                               u_known, touch);
 }
 
 // ---- multi-GPU: the pattern of the rows a rank keeps (owned nodes, one ghost layer, prescribed nodes) ----
