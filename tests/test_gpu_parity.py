@@ -1074,3 +1074,39 @@ def test_on_chip_edge_blocks_are_refused_where_a_row_does_not_fit(built, monkeyp
             st = c.stats()
         assert st["cg_kernel"] == 2 and st["edge_blocks"] == 0, mesh.name
         assert rel(out["u"], ref["u"]) <= TOL_U, mesh.name
+
+
+def _plate_with_removed_cells(nx, seed, rects, p_random):
+    """plate(nx) minus axis-parallel rectangles of cells and, with probability p_random each, single cells: rectangles keep
+    every node's triangles in one fan (the mesh stays eligible for edge blocks); a single removed cell can leave a node
+    whose two remaining corner cells touch only at the node -- two fans -- which must send the mesh to the triangle walk."""
+    rng = np.random.default_rng(seed)
+    xy, tri, cx, cy = meshgen._grid(nx, nx, 1.0, 1.0)
+    keep = np.ones(cx.shape[0], dtype=bool)
+    for _ in range(rects):
+        x0, y0 = rng.uniform(0.1, 0.7, 2)
+        w, h = rng.uniform(0.05, 0.2, 2)
+        keep &= ~((cx > x0) & (cx < x0 + w) & (cy > y0) & (cy < y0 + h))
+    if p_random > 0:
+        inner = (cx > 0.1) & (cx < 0.9) & (cy > 0.1) & (cy < 0.9)
+        keep &= ~(inner & (rng.uniform(size=cx.shape[0]) < p_random))
+    return meshgen._compact(xy, tri, keep, f"cells_{nx}_{seed}")
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_on_chip_kernel_choice_on_random_cell_patterns(built, seed, monkeypatch):
+    """Random structured meshes: rectangles of removed cells (every node star stays one fan: edge blocks) and, for the odd
+    seeds, scattered single cells as well (nodes with two fans appear: triangle walk).  Either way the oracle's answer."""
+    monkeypatch.setenv("MAG_TUNE_PERSIST_MIN_K", "1")
+    mesh = _plate_with_removed_cells(72 + 8 * seed, seed, rects=2 + seed % 3, p_random=0.01 if seed % 2 else 0.0)
+    p = meshgen.config_fixed_left_pull_right(meshgen.shuffle(mesh, seed))
+    ref = oracle_run(p)
+    with Context(device=0, tile_nodes=512) as c:
+        out = c.solve(p)
+        st = c.stats()
+    assert st["cg_kernel"] == 2, seed
+    if seed % 2 == 0:
+        assert st["edge_blocks"] == 1, seed
+    assert out["converged"] == 1 and abs(out["iterations"] - ref["iterations"]) <= max(3, ref["iterations"] // 50), seed
+    for key in ("u", "f", "stress"):
+        assert rel(out[key], ref[key]) <= TOL_U, (seed, key)
