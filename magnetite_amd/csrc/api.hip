@@ -471,7 +471,9 @@ int ensure_order(mag_ctx *ctx)
         const int pthreads = magk::persist_threads();
         const int kmax = magk::persist_tiles_per_wg(B, pthreads);
         const int32_t tiles_max = (T + R - 1) / R; // the most tiles any rank runs
-        const int k = cus > 0 ? (tiles_max + cus - 1) / cus : 0;
+        int k = cus > 0 ? (tiles_max + cus - 1) / cus : 0;
+        // rehearsals: several ranks share ONE GPU and must all be co-resident -- fewer, fuller workgroups per rank
+        if (const char *e = getenv("MAG_TUNE_PERSIST_K")) k = std::max(k, atoi(e));
         // Measured against the streaming kernel on the same 512-node tiles the on-chip kernel wins from one tile per
         // workgroup up (6.2 vs 7.9 us per iteration at 115 tiles, 12.6 vs 20.3 at 982); with 256-node tiles it does not
         // (and eight of them rarely fit the LDS), so those only run it when a test asks (MAG_TUNE_PERSIST_MIN_K=1).

@@ -359,8 +359,11 @@ __device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsi
         }
         return false;
     };
-    __builtin_amdgcn_s_sleep(20);
-    __builtin_amdgcn_s_sleep(20);
+#ifndef MAG_PERSIST_SLEEP_MG
+#define MAG_PERSIST_SLEEP_MG 20
+#endif
+    __builtin_amdgcn_s_sleep(MAG_PERSIST_SLEEP_MG);
+    __builtin_amdgcn_s_sleep(MAG_PERSIST_SLEEP_MG);
     if (lead) {
         // (1) this rank's records (and this workgroup's own halo values)
         bool have_rec = tid >= 2 * grid, done = false;
