@@ -830,7 +830,74 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         }
     }
     // halo entries of the workgroup's tiles, in tile order, dealt out round-robin: thread t takes entries t, t + 512
-    {
+    if (kPersistSiblings && !MG) {
+        // Single GPU: about half of the entries are owned by sibling tiles and need no halo copy.  The ones that do are
+        // COMPACTED before they are dealt out (same order): ~250 of them fill the first round of four waves, where the
+        // uncompacted list left a few live lanes in both rounds of all eight -- every one of those wave-rounds pays the LDS
+        // operations of the halo update and the instructions of the halo fetch in every iteration.
+        const int32_t t_first = blockIdx.x * P.tiles_per_wg, t_end = P.T;
+        int32_t cg[NH], cl[NH];
+#pragma unroll
+        for (int e = 0; e < NH; ++e) {
+            cg[e] = -1;
+            cl[e] = 0;
+            int32_t rem = tid + kPersistThreads * e;
+            for (int l = 0; l < P.tiles_per_wg && t_first + l < t_end; ++l) {
+                const TileMeta tm = P.meta[t_first + l];
+                if (rem < tm.nh) {
+                    const int32_t g = P.halo_g[tm.hoff + rem];
+                    const int32_t ot = g / B, ol = ot - t_first;
+                    // a sibling tile owns it: this tile's walks read the owner's slots (rows all in the registers only)
+                    const bool sibling = tm.ent <= 2 * kPersistRegs && ol >= 0 && ol < P.tiles_per_wg && ot < t_end;
+                    if (!sibling) {
+                        cg[e] = g;
+                        cl[e] = l * tile_words + rem;
+                    }
+                    break;
+                }
+                rem -= tm.nh;
+            }
+        }
+        int32_t *s_cnt = (int32_t *)s_red; // live entries per (round, wave), then their exclusive prefix
+        int2 *s_list = (int2 *)s_rec;      // 2 * THREADS entries at most: 8 KB, the record staging area (free until the exchange)
+        constexpr int NW8 = kPersistThreads / 64;
+        int32_t pos[NH];
+#pragma unroll
+        for (int e = 0; e < NH; ++e) {
+            const unsigned long long live = __ballot(cg[e] >= 0);
+            pos[e] = __builtin_amdgcn_mbcnt_hi((unsigned)(live >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)live, 0u));
+            if ((tid & 63) == 0) s_cnt[e * NW8 + (tid >> 6)] = __popcll(live);
+        }
+        __syncthreads();
+        int32_t total = 0;
+#pragma unroll
+        for (int e = 0; e < NH; ++e) {
+            int32_t base = 0;
+            for (int k = 0; k < e * NW8 + (tid >> 6); ++k) base += s_cnt[k];
+            if (cg[e] >= 0) s_list[base + pos[e]] = make_int2(cg[e], cl[e]);
+        }
+        for (int k = 0; k < NH * NW8; ++k) total += s_cnt[k];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < NH; ++e) {
+            hg[e] = -1;
+            hloc[e] = 0;
+            const int32_t c = tid + kPersistThreads * e;
+            if (c < total) {
+                const int2 ent2 = s_list[c];
+                hg[e] = ent2.x;
+                hloc[e] = ent2.y;
+                const int32_t l = ent2.y / tile_words, rem = ent2.y - l * tile_words;
+                const TileMeta tm = P.meta[t_first + l];
+                double2 *xy = smem + (size_t)l * tile_words;
+                if (!EB) xy[B + rem] = P.halo_xy[tm.hoff + rem];
+                const double2 hb = P.bP[hg[e]];
+                xy[2 * cap + rem] = make_double2(-hb.x, -hb.y); // halo r
+                xy[cap + B + rem] = make_double2(0.0, 0.0);     // halo p: its slot in the p image
+            }
+        }
+        __syncthreads(); // s_red and s_rec go back to their day jobs
+    } else {
         const int32_t t_first = (MG ? P.t0 : 0) + blockIdx.x * P.tiles_per_wg, t_end = MG ? P.t1 : P.T;
 #pragma unroll
         for (int e = 0; e < NH; ++e) {
@@ -842,13 +909,6 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
                 if (rem < tm.nh) {
                     double2 *xy = smem + (size_t)l * tile_words;
                     hg[e] = P.halo_g[tm.hoff + rem];
-                    {
-                        const int32_t ot = hg[e] / B, ol = ot - t_first;
-                        if (kPersistSiblings && !MG && tm.ent <= 2 * kPersistRegs && ol >= 0 && ol < P.tiles_per_wg && ot < t_end) {
-                            hg[e] = -1; // a sibling tile owns it: this tile's walks read the owner's slots
-                            break;
-                        }
-                    }
                     hloc[e] = l * tile_words + rem;
                     if (!EB) xy[B + rem] = P.halo_xy[tm.hoff + rem];
                     const double2 hb = P.bP[hg[e]];
