@@ -1176,7 +1176,8 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         }
         MAG_STAMP(3) // workgroup sums (wave trees, barrier, eight waves in order) + record published
 #ifdef MAG_PERSIST_STAMPS
-        unsigned long long xs_[3] = {0, 0, 0};
+        unsigned long long *xs_ = stamp_sum + kStampPhases + 2; // (LDS as well: no stack object, no scratch in the diagnostic build)
+        if (stamping) xs_[0] = xs_[1] = xs_[2] = 0;
         if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec)
                : !persist_exchange<NH, EB>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk, stamping ? xs_ : nullptr))
             return;
