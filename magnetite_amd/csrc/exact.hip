@@ -569,7 +569,9 @@ __device__ inline void k_store(double *dst, double2 v)
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
     u4 t;
     __builtin_memcpy(&t, &v, 16);
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(t) : "memory");
+    // (s_nop: the registers of a store of more than 8 bytes must not be rewritten in the next two cycles; the compiler
+    // keeps that distance for its own stores and cannot see into this one)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(t) : "memory");
 #else
     *(double2 *)dst = v;
 #endif
