@@ -248,21 +248,19 @@ __device__ inline void ring_walk_cached(const uint32_t (&w)[NW], const uint32_t 
 // K_ac of the triangle before it -- a node's triangles become blocks, and a ring step is one LDS gather of p, two
 // subtractions and four FMAs instead of the ~23 fp64 operations and two gathers of fan_force_w.  NB block entries per
 // node: the NB - 1 triangles between them, and triangle NB as well when it CLOSES the fan onto entry 0 (a closed fan of
-// valence NB -- the rule on structured meshes -- is then NB blocks and nothing else); whatever is left is walked as
-// triangles (`tail`).  Only the SYMMETRIC part of a block is kept (three numbers): the antisymmetric part of one
-// triangle's contribution is
+// valence NB -- the rule on structured meshes -- is then NB blocks and nothing else).  Rows this does not cover (several
+// fans at a node, more entries) never get here: k_ring16 flags the mesh and it keeps the triangle walk.
+// Only the SYMMETRIC part of a block is kept (three numbers): the antisymmetric part of one triangle's contribution is
 //     -kappa J for the entry before it, +kappa J for the entry after it,   kappa = (h - nu) c0 / 2,  J = [[0, 1], [-1, 0]]
 // whatever its shape (K12 - K21 = (h - nu) w (ba dc.x + ga dc.y) = -(h - nu) w 2A, and w = c0 / 2A), so over a fan the
-// antisymmetric parts telescope to kappa J (u_last - u_first): nothing for a fan closed inside the blocks, two
-// subtractions and two FMAs per NODE otherwise.  Rows whose block triangles are not one fan (a break bit on an entry
-// that is not padding) do not telescope: such tiles keep the triangle walk (the caller decides per tile, ring_has_break).
+// antisymmetric parts telescope to kappa J (u_last - u_first): nothing for a closed fan, two subtractions and two FMAs per
+// NODE otherwise (tests/test_edge_block_algebra.py restates this in numpy).
 // The blocks are filled by applying fan_force_w, with the weight ring_weights computes, to unit vectors: the same
 // arithmetic as the triangle walk up to the order of the additions.
-// Returns bit 0: triangle NB closed the fan and is folded in; bit 1: the row has triangles the blocks do not cover.
 // XY: coordinates of a ring entry's node, by its (masked) id
 template <int NW, int NB, uint32_t IDMASK = 0xfffu, class XY>
-__device__ inline uint32_t ring_blocks(const uint32_t (&w)[NW], int32_t nent, XY &&xy_of, const double2 ca,
-                                       double c0, double nu, double h, double (&kb)[3 * NB])
+__device__ inline void ring_blocks(const uint32_t (&w)[NW], int32_t nent, XY &&xy_of, const double2 ca, double c0, double nu,
+                                   double h, double (&kb)[3 * NB])
 {
     static_assert(NB + 1 <= 2 * NW, "block entries come from the ring words held in registers");
     auto entry = [&](int k) { return (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu); };
@@ -274,7 +272,6 @@ __device__ inline uint32_t ring_blocks(const uint32_t (&w)[NW], int32_t nent, XY
         pd = make_double2(cxy.x - ca.x, cxy.y - ca.y);
     }
     const double2 z = make_double2(0.0, 0.0), ex = make_double2(1.0, 0.0), ey = make_double2(0.0, 1.0);
-    uint32_t out = 0;
 #pragma unroll
     for (int k = 1; k <= NB; ++k)
         if (k < nent) {
@@ -291,28 +288,20 @@ __device__ inline uint32_t ring_blocks(const uint32_t (&w)[NW], int32_t nent, XY
                 fan_force_w<double2, double>(pd, ey, d, z, wt, nu, h, b01, b11);
                 fan_force_w<double2, double>(pd, z, d, ex, wt, nu, h, c00, c10); // K_ac
                 fan_force_w<double2, double>(pd, z, d, ey, wt, nu, h, c01, c11);
-                constexpr int jc = 0; // (k == NB: the closing entry is entry 0)
+                const int jc = k < NB ? k : 0; // (k == NB: the closing entry is entry 0)
                 kb[3 * (k - 1) + 0] += b00;
                 kb[3 * (k - 1) + 1] += 0.5 * (b01 + b10);
                 kb[3 * (k - 1) + 2] += b11;
-                kb[3 * (k < NB ? k : jc) + 0] += c00;
-                kb[3 * (k < NB ? k : jc) + 1] += 0.5 * (c01 + c10);
-                kb[3 * (k < NB ? k : jc) + 2] += c11;
-                if (k == NB) out |= 1u;
-            } else if (closes) {
-                out |= 2u;
+                kb[3 * jc + 0] += c00;
+                kb[3 * jc + 1] += 0.5 * (c01 + c10);
+                kb[3 * jc + 2] += c11;
             }
             pd = d;
         }
-#pragma unroll
-    for (int k = NB + 1; k < 2 * NW; ++k)
-        if (k < nent && !(entry(k) & 0x8000u)) out |= 2u;
-    if (nent > 2 * NW) out |= 2u; // entries in memory: not looked at here
-    return out;
 }
 
 // Block entries the tile's rows do not reach repeat the last one (as padding does inside the rows, with a zero block):
-// ring_walk_blocks<.., ALL> then gathers all NB entries without a test -- every one is a slot somebody initialised.
+// ring_walk_blocks then gathers all NB entries without a test -- every one is a slot somebody initialised.
 template <int NW, int NB, uint32_t IDMASK = 0xfffu>
 __device__ inline void ring_pad_entries(uint32_t (&w)[NW], int32_t nent)
 {
@@ -325,29 +314,11 @@ __device__ inline void ring_pad_entries(uint32_t (&w)[NW], int32_t nent)
     }
 }
 
-// a break bit that is not padding (padding repeats the previous entry's slot) on one of the entries 1 .. NB - 1
+// The walk over a node's NB blocks: all NB gathers of p in one straight-line block (ring_pad_entries made every entry a
+// valid slot; a zero block adds nothing), one FMA per term.  folded: the fan closes inside the blocks (nothing to telescope).
 template <int NW, int NB, uint32_t IDMASK = 0xfffu>
-__device__ inline bool ring_has_break(const uint32_t (&w)[NW], int32_t nent)
-{
-    auto entry = [&](int k) { return (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu); };
-    bool bad = false;
-#pragma unroll
-    for (int k = 1; k < NB; ++k)
-        if (k < nent) {
-            const uint32_t e = entry(k), ep = entry(k - 1);
-            bad |= (e & 0x8000u) && ((e & IDMASK) != (ep & IDMASK));
-        }
-    return bad;
-}
-
-// folded: ring_blocks' bit 0 for this row; tail: some row of the tile has triangles beyond the blocks (a scalar)
-// ALL: every one of the NB entries is gathered without a test (ring_blocks made them valid slots): one straight-line block,
-// the gathers issue together.
-template <int NW, int NB, uint32_t IDMASK = 0xfffu, bool ALL = false>
-__device__ inline void ring_walk_blocks(const uint32_t (&w)[NW], const uint32_t *more, int32_t stride, int32_t nent,
-                                        const double2 *s_xy, const double2 *s_p, const double2 ca, const double2 pa,
-                                        double c0, double nu, double h, double kappa, bool folded, bool tail,
-                                        const double (&kb)[3 * NB], double &fx, double &fy, uint32_t toff = 0)
+__device__ inline void ring_walk_blocks(const uint32_t (&w)[NW], const double2 *s_p, const double2 pa, double kappa,
+                                        bool folded, const double (&kb)[3 * NB], double &fx, double &fy)
 {
     auto entry = [&](int k) { return (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu); };
     double2 u0, ul;
@@ -359,44 +330,16 @@ __device__ inline void ring_walk_blocks(const uint32_t (&w)[NW], const uint32_t 
         ul = u0;
     }
 #pragma unroll
-    for (int k = 1; k < NB; ++k)
-        if (ALL || k < nent) { // nent: a scalar
-            const double2 cp = s_p[entry(k) & IDMASK];
-            const double2 u = make_double2(cp.x - pa.x, cp.y - pa.y);
-            fx = fma(kb[3 * k + 1], u.y, fma(kb[3 * k], u.x, fx));
-            fy = fma(kb[3 * k + 2], u.y, fma(kb[3 * k + 1], u.x, fy));
-            ul = u;
-        }
+    for (int k = 1; k < NB; ++k) {
+        const double2 cp = s_p[entry(k) & IDMASK];
+        const double2 u = make_double2(cp.x - pa.x, cp.y - pa.y);
+        fx = fma(kb[3 * k + 1], u.y, fma(kb[3 * k], u.x, fx));
+        fy = fma(kb[3 * k + 2], u.y, fma(kb[3 * k + 1], u.x, fy));
+        ul = u;
+    }
     const double kap = folded ? 0.0 : kappa; // a fan closed inside the blocks: its antisymmetric parts cancel
     fx += kap * (ul.y - u0.y);               // otherwise they telescope to kappa J (u_last - u_first)
     fy -= kap * (ul.x - u0.x);
-    if (tail && nent > NB) { // triangles beyond the blocks: evaluated as triangles, from the last block entry on
-        double2 pd, pu = ul;
-        {
-            const double2 cxy = s_xy[entry(NB - 1) & IDMASK];
-            pd = make_double2(cxy.x - ca.x, cxy.y - ca.y);
-        }
-        auto tri = [&](uint32_t e, bool skip) {
-            const uint32_t id = e & IDMASK;
-            const double2 cxy = s_xy[id], cp = s_p[id];
-            const double2 d = make_double2(cxy.x - ca.x, cxy.y - ca.y), u = make_double2(cp.x - pa.x, cp.y - pa.y);
-            double dfx = 0.0, dfy = 0.0;
-            fan_force<double2, double>(pd, pu, d, u, c0, nu, h, dfx, dfy);
-            const bool closes = !(e & 0x8000u) && !skip;
-            fx += closes ? dfx : 0.0;
-            fy += closes ? dfy : 0.0;
-            pd = d;
-            pu = u;
-        };
-#pragma unroll
-        for (int k = NB; k < 2 * NW; ++k)
-            if (k < nent) tri(entry(k), k == NB && folded);
-        for (int32_t k = 2 * NW; k < nent; ++k) {
-            const uint32_t ww = more[(int64_t)(k >> 1) * stride];
-            const uint32_t e0 = (k & 1) ? (ww >> 16) : (ww & 0xffffu);
-            tri(((e0 & 0xfffu) + toff) | (e0 & 0x8000u), false);
-        }
-    }
 }
 
 } // namespace magk

@@ -651,12 +651,6 @@ constexpr bool kPersistEdgeBlocks = MAG_PERSIST_EDGE_BLOCKS != 0; // edge blocks
 #ifndef MAG_PERSIST_EB_PACK
 #define MAG_PERSIST_EB_PACK 1
 #endif
-#ifndef MAG_PERSIST_EB_ALL
-#define MAG_PERSIST_EB_ALL 1
-#endif
-#ifndef MAG_PERSIST_EB_FENCE
-#define MAG_PERSIST_EB_FENCE 1
-#endif
 constexpr int kPersistBlockEntries = MAG_PERSIST_NB; // block entries per node: a closed fan of valence 6 is exactly six blocks
 constexpr int kPersistNh = 2;   // halo entries per thread: a workgroup's tiles may carry 2 * THREADS halo nodes in all
 constexpr int persist_npt(int threads) { return threads == 768 ? 3 : 4; } // nodes per lane
@@ -1112,11 +1106,8 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
                 if (nent > 0) { // entries are biased slots relative to this tile (see the remap at the top)
                     const uint32_t toff = (uint32_t)(3 * tile_words);
                     if (BLOCKS)
-                        ring_walk_blocks<kPersistRegs, NB, 0x7fffu, MAG_PERSIST_EB_ALL != 0>(w[s], P.ell16 + ell_off[s], B, nent, xy - 3 * tile_words,
-                                                                    pim - 3 * tile_words, ca, pa, c0, nu, h, kappa,
-                                                                    (flags[s] & 32u) != 0, false,
-                                                                    *reinterpret_cast<const double(*)[3 * NB]>(&wgt[s][0]),
-                                                                    fx, fy, toff);
+                        ring_walk_blocks<kPersistRegs, NB, 0x7fffu>(w[s], pim - 3 * tile_words, pa, kappa, (flags[s] & 32u) != 0,
+                                                                    *reinterpret_cast<const double(*)[3 * NB]>(&wgt[s][0]), fx, fy);
                     else if (CACHED)
                         ring_walk_cached<kPersistRegs, NCW, 0x7fffu>(w[s], P.ell16 + ell_off[s], B, nent, xy - 3 * tile_words, pim - 3 * tile_words,
                                                                      ca, pa, c0, nu, h, *reinterpret_cast<const double(*)[NCW]>(&wgt[s][0]),
@@ -1143,11 +1134,6 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             acc[1] += pa.x * fx + pa.y * fy;
             acc[2] += rv.x * fx + rv.y * fy;
             acc[3] += fx * fx + fy * fy;
-#if MAG_PERSIST_EB_FENCE
-            // the edge-block instantiation has no register to spare: keep the scheduler from starting the next slot's
-            // gathers inside this one (one spilled register in the loop costs a memory round trip per iteration)
-            if (EB) __builtin_amdgcn_sched_barrier(0);
-#endif
         }
 #if MAG_PERSIST_PRIO
         __builtin_amdgcn_s_setprio(0);
