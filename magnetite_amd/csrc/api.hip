@@ -1211,9 +1211,10 @@ int cg_phase_persist(mag_ctx *ctx)
     HIPCHK(hipMemsetAsync(ctx->fstate.p, 0, sizeof(FusedState), s));
     const int R = ctx->comm.nranks;
     const bool mg = R > 1;
-    if (!mg) // which nodes are read through memory at all, with persist_k tiles per workgroup (the others publish nothing)
-        magk::mark_external(ctx->halo_g.as<int32_t>(), ctx->tmeta.as<magk::TileMeta>(), ctx->T, ctx->B, ctx->persist_k,
-                            ctx->maskP.as<uint8_t>(), s);
+    // which nodes are read through memory at all by this rank's tiles, with persist_k tiles per workgroup (the others publish
+    // nothing on this GPU; what other ranks read goes through the inboxes)
+    magk::mark_external(ctx->halo_g.as<int32_t>(), ctx->tmeta.as<magk::TileMeta>(), ctx->t0, ctx->t1, ctx->B, ctx->persist_k,
+                        ctx->maskP.as<uint8_t>(), s);
     magk::PersistParams P = {};
     P.nranks = 1;
     if (mg) {

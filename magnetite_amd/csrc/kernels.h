@@ -370,7 +370,7 @@ int persist_stamp_words();   // words per workgroup in PersistParams::stamps
 bool persist_stamps_built(); // the library was compiled with -DMAG_PERSIST_STAMPS
 void mark_published(const int32_t *halo_g, int64_t halo_total, uint8_t *maskP, hipStream_t s);
 // bit 3: read through memory by a workgroup of the on-chip kernel (k tiles per workgroup) other than the owner's
-void mark_external(const int32_t *halo_g, const TileMeta *meta, int32_t T, int32_t B, int32_t k, uint8_t *maskP,
+void mark_external(const int32_t *halo_g, const TileMeta *meta, int32_t t0, int32_t t1, int32_t B, int32_t k, uint8_t *maskP,
                    hipStream_t s);
 
 // ---- fp32 leg of BASELINE config 5 (fp64 vs fp32 CG tolerance sweep): the fused iteration with the CG state, the

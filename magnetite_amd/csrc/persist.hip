@@ -759,7 +759,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             flags.set(s, flags[s] | 16u | (mk & 7u));
             // bit 3 of the mask (k_mark_external): read through memory by a tile of ANOTHER workgroup, or by a sibling tile
             // that keeps its halo copies; a node only its siblings read through their LDS slots publishes nothing
-            if (kPersistSiblings && !MG && !(mk & 8u)) flags.set(s, flags[s] & ~4u);
+            if (kPersistSiblings && !(mk & 8u)) flags.set(s, flags[s] & ~4u);
             acc[0] += b.x * b.x + b.y * b.y;
         } else {
             xy[lt] = make_double2(0.0, 0.0);
@@ -787,8 +787,9 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         // into the walks.)
         {
             const int32_t t_first = (MG ? P.t0 : 0) + blockIdx.x * P.tiles_per_wg, t_end = MG ? P.t1 : P.T;
-            // (single-GPU instantiation only: a workgroup of several tiles next to other ranks cannot be rehearsed on one GPU)
-            const bool short_rows = kPersistSiblings && !MG && tm.ent <= 2 * kPersistRegs;
+            // (several ranks: siblings are tiles of the same workgroup, hence of the same rank; rehearsed with two ranks
+            // sharing one GPU at four tiles per workgroup, scripts/mg_share_ab.sh)
+            const bool short_rows = kPersistSiblings && tm.ent <= 2 * kPersistRegs;
             auto remap = [&](uint32_t e) -> uint32_t {
                 if (e == 0xffffu) return e;
                 const uint32_t lid = e & 0xfffu;
@@ -824,12 +825,12 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         }
     }
     // halo entries of the workgroup's tiles, in tile order, dealt out round-robin: thread t takes entries t, t + 512
-    if (kPersistSiblings && !MG) {
-        // Single GPU: about half of the entries are owned by sibling tiles and need no halo copy.  The ones that do are
+    if (kPersistSiblings) {
+        // About half of the entries are owned by sibling tiles and need no halo copy.  The ones that do are
         // COMPACTED before they are dealt out (same order): ~250 of them fill the first round of four waves, where the
         // uncompacted list left a few live lanes in both rounds of all eight -- every one of those wave-rounds pays the LDS
         // operations of the halo update and the instructions of the halo fetch in every iteration.
-        const int32_t t_first = blockIdx.x * P.tiles_per_wg, t_end = P.T;
+        const int32_t t_first = (MG ? P.t0 : 0) + blockIdx.x * P.tiles_per_wg, t_end = MG ? P.t1 : P.T;
         int32_t cg[NH], cl[NH];
 #pragma unroll
         for (int e = 0; e < NH; ++e) {
@@ -888,6 +889,10 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
                 const double2 hb = P.bP[hg[e]];
                 xy[2 * cap + rem] = make_double2(-hb.x, -hb.y); // halo r
                 xy[cap + B + rem] = make_double2(0.0, 0.0);     // halo p: its slot in the p image
+                if (MG) { // a node another rank owns: its q comes through the window (slot s encoded as -2 - s)
+                    const int32_t hs = P.halo_qslot[tm.hoff + rem];
+                    if (hs >= 0) hg[e] = -2 - hs;
+                }
             }
         }
         __syncthreads(); // s_red and s_rec go back to their day jobs
@@ -1476,26 +1481,27 @@ bool persist_stamps_built()
 #endif
 }
 
-// bit 3 of the node mask, for the on-chip kernel with `k` tiles per workgroup: some tile reads this node THROUGH MEMORY -- a
-// tile of another workgroup, or a sibling tile whose rows do not all fit the registers (it keeps its halo copies).  One
-// block per reading tile.
+// bit 3 of the node mask, for the on-chip kernel with `k` tiles per workgroup: some tile of THIS rank's range [t0, t1) reads
+// the node THROUGH MEMORY -- a tile of another workgroup, or a sibling tile whose rows do not all fit the registers (it
+// keeps its halo copies).  One block per reading tile.  (Tiles of other ranks read through the inboxes, not through this
+// GPU's granules: they mark nothing here.)
 __global__ void __launch_bounds__(256) k_mark_external(const int32_t *halo_g, const TileMeta *meta, int32_t B, int32_t k,
-                                                       int32_t max_reg_entries, uint8_t *maskP)
+                                                       int32_t max_reg_entries, int32_t t0, int32_t t1, uint8_t *maskP)
 {
-    const int32_t t = blockIdx.x;
+    const int32_t t = t0 + (int32_t)blockIdx.x;
     const TileMeta tm = meta[t];
     for (int32_t h = threadIdx.x; h < tm.nh; h += 256) {
         const int64_t g = halo_g[tm.hoff + h];
         const int32_t ot = (int32_t)(g / B);
-        if (ot / k != t / k || tm.ent > max_reg_entries)
-            atomicOr((unsigned int *)(maskP + (g & ~(int64_t)3)), 8u << (8 * (g & 3)));
+        const bool sibling = ot >= t0 && ot < t1 && (ot - t0) / k == (t - t0) / k && tm.ent <= max_reg_entries;
+        if (!sibling) atomicOr((unsigned int *)(maskP + (g & ~(int64_t)3)), 8u << (8 * (g & 3)));
     }
 }
 
-void mark_external(const int32_t *halo_g, const TileMeta *meta, int32_t T, int32_t B, int32_t k, uint8_t *maskP,
+void mark_external(const int32_t *halo_g, const TileMeta *meta, int32_t t0, int32_t t1, int32_t B, int32_t k, uint8_t *maskP,
                    hipStream_t s)
 {
-    if (T > 0) k_mark_external<<<T, 256, 0, s>>>(halo_g, meta, B, k, 2 * kPersistRegs, maskP);
+    if (t1 > t0) k_mark_external<<<t1 - t0, 256, 0, s>>>(halo_g, meta, B, k, 2 * kPersistRegs, t0, t1, maskP);
 }
 
 // bit 2 of the node mask: some tile reads this node through its halo list, so its owner must publish q

@@ -186,6 +186,27 @@ def test_config4_four_ranks_at_baseline_size_against_the_oracle_fixture(built, e
     assert d["verify"]["ok_on_every_rank"] is True and d["capped"] is False
 
 
+def test_on_chip_kernels_of_two_ranks_with_four_tiles_per_workgroup_against_the_oracle_fixture(built):
+    """The multi-GPU on-chip kernel at the load it has on a node -- four 512-node tiles per workgroup, sibling tiles reading
+    each other's LDS slots, the live halo entries compacted, nodes only siblings read publishing nothing locally -- which the
+    8-rank rehearsals (one tile per workgroup) never reach: the 1M-triangle mesh of BASELINE config 3 split over TWO ranks that
+    share the one GPU (MAG_TUNE_PERSIST_K=4 makes each rank's grid 123 workgroups, so both launches are co-resident),
+    device inboxes, every rank against the oracle's sampled solution (5389 iterations, u <= 1e-8)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MAG_TUNE_PERSIST_K"] = "4"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--partition",
+                        "strong", "--workload", "hole1m", "--exchange", "inboxes", "--steps", "1", "--warmup", "1",
+                        "--op-reps", "20", "--no-cpu-baseline", "--no-hbm-resident", "--check-fixture"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    fp = d["fixture_parity"]
+    assert fp["ok"] is True and fp["ok_on_every_rank"] is True, fp
+    assert fp["iterations"] == fp["oracle_iterations"] == 5389 and fp["rel_l2_u_sampled"] <= 1e-8
+    assert d["config"]["cg_kernel"] == 2 and d["config"]["exchange_kind"] == 2 and d["fallback"] is False
+    assert d["verify"]["ok_on_every_rank"] is True and d["capped"] is False
+
+
 def test_bench_refuses_to_pass_a_capped_solve_for_a_result(built):
     """mag_run returns MAG_OK at the iteration cap (solver.rs:149-176 returns Ok(best_param)); a bench line measured on
     such steps is marked and the process exits non-zero"""
