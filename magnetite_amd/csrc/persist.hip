@@ -750,11 +750,9 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         flags.set(s, 8);
         if (nd < P.N) {
             const double2 b = P.bP[nd];
-            if (EB) xy[lt] = make_double2(-b.x, -b.y); // r lives where the triangle walk keeps the coordinates
-            else {
-                r[s] = make_double2(-b.x, -b.y);
-                xy[lt] = P.xyP[nd];
-            }
+            r[s] = make_double2(-b.x, -b.y);
+            // edge blocks: the coordinates are never read; q lives in their place (and the blocks in q's registers)
+            xy[lt] = EB ? make_double2(0.0, 0.0) : P.xyP[nd];
             const uint32_t mk = P.maskP[nd];
             flags.set(s, flags[s] | 16u | (mk & 7u));
             // bit 3 of the mask (k_mark_external): read through memory by a tile of ANOTHER workgroup, or by a sibling tile
@@ -981,7 +979,11 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
                                                          *reinterpret_cast<double(*)[NCW]>(&wgt[s][0]));
         }
     }
-    constexpr bool RL = EB; // r in LDS (in the coordinates' place) instead of registers
+    // Edge-block instantiation: q in LDS, in the coordinates' place, instead of registers (the blocks need them).  q rather
+    // than r: q is written once (end of the node's walk) and read once (r += alpha q) per iteration, r is read in the
+    // update, the dots and the deferred x update and written in the update -- two LDS operations per node and iteration
+    // instead of four.
+    constexpr bool QL = EB;
     double target = P.tol, bb = 0.0;
     long long j = 0;
     int verdict = 0; // 1 converged, 2 iteration cap, 3 non-finite
@@ -1053,13 +1055,11 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
                 xo.y += alpha * po.y;
                 xs[lt] = xo;
             }
-            double2 rv = RL ? xy[lt] : r[s];
-            rv.x += alpha * q[s].x;
-            rv.y += alpha * q[s].y;
-            if (RL) xy[lt] = rv;
-            else r[s] = rv;
-            pn.x = -rv.x + beta * po.x;
-            pn.y = -rv.y + beta * po.y;
+            const double2 qv = QL ? xy[lt] : q[s];
+            r[s].x += alpha * qv.x;
+            r[s].y += alpha * qv.y;
+            pn.x = -r[s].x + beta * po.x;
+            pn.y = -r[s].y + beta * po.y;
             pim[lt] = pn;
         }
 #pragma unroll
@@ -1125,19 +1125,20 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             }
             if ((flags[s] & 1) || !(flags[s] & 16)) fx = 0.0;
             if ((flags[s] & 2) || !(flags[s] & 16)) fy = 0.0;
-            q[s] = make_double2(fx, fy);
+            const double2 qn = make_double2(fx, fy);
+            if (QL) t_xy(s)[lt] = qn;
+            else q[s] = qn;
 #if MAG_PERSIST_SADDR
             if ((flags[s] & 20) == 20) // (2 x 32 N bytes of granules: below 4 GB for every mesh the chip can hold)
-                put_granules_at(P.qg, 32u * ((uint32_t)(par ^ 1) * (uint32_t)P.N + (uint32_t)node_of(s)), epoch + 1, q[s]);
+                put_granules_at(P.qg, 32u * ((uint32_t)(par ^ 1) * (uint32_t)P.N + (uint32_t)node_of(s)), epoch + 1, qn);
 #else
-            if ((flags[s] & 20) == 20) put_granules(P.qg + 4 * ((int64_t)(par ^ 1) * P.N + node_of(s)), epoch + 1, q[s]);
+            if ((flags[s] & 20) == 20) put_granules(P.qg + 4 * ((int64_t)(par ^ 1) * P.N + node_of(s)), epoch + 1, qn);
 #endif
             if (MG && oslot[s] >= 0)
-                publish_q(P, par ^ 1, oslot[s], oreaders[s], epoch + 1, q[s]);
-            const double2 rv = RL ? xy[lt] : r[s];
-            acc[0] += rv.x * rv.x + rv.y * rv.y;
+                publish_q(P, par ^ 1, oslot[s], oreaders[s], epoch + 1, qn);
+            acc[0] += r[s].x * r[s].x + r[s].y * r[s].y;
             acc[1] += pa.x * fx + pa.y * fy;
-            acc[2] += rv.x * fx + rv.y * fy;
+            acc[2] += r[s].x * fx + r[s].y * fy;
             acc[3] += fx * fx + fy * fy;
         }
 #if MAG_PERSIST_PRIO
@@ -1158,7 +1159,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
                 if (!(flags[s] & 8)) continue;
                 const int lt = t_lt(s);
                 double2 *xy = t_xy(s), *pim = xy + cap, *xs = pim + cap + maxh;
-                const double2 pj = pim[lt], rv = RL ? xy[lt] : r[s];
+                const double2 pj = pim[lt], rv = r[s];
                 double2 xo = xs[lt];
                 xo.x += ab * (pj.x + rv.x);
                 xo.y += ab * (pj.y + rv.y);
