@@ -142,9 +142,11 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
 #endif
     // The edge-block instantiation reaches this point ~1.5 us earlier in the iteration; re-swept for it (us per iteration at
     // 1M / 100k triangles, one box): 4+2 6.79, 6+4 6.69 / 4.50, 8+6 6.63 / 4.37, 10+8 6.66 / 4.32, 12+10 6.73 / 4.39, 14+12 6.81.
+    // After the workgroup's final sums became a cross-lane chain (persist_block_sum: the record leaves ~0.4 us earlier):
+    // 2+0 6.40 / 4.28, 4+2 6.11 / 4.26, 4+4 6.09 / 4.12, 6+4 6.09 / 4.05, 8+6 6.15 / 4.09, 10+8 6.23 / 4.14, 12+10 6.32 / 4.26.
 #ifndef MAG_PERSIST_SLEEP1_EB
-#define MAG_PERSIST_SLEEP1_EB 8
-#define MAG_PERSIST_SLEEP2_EB 6
+#define MAG_PERSIST_SLEEP1_EB 6
+#define MAG_PERSIST_SLEEP2_EB 4
 #endif
     __builtin_amdgcn_s_sleep(EB ? MAG_PERSIST_SLEEP1_EB : MAG_PERSIST_SLEEP1);
     if ((EB ? MAG_PERSIST_SLEEP2_EB : MAG_PERSIST_SLEEP2) > 0) __builtin_amdgcn_s_sleep(EB ? MAG_PERSIST_SLEEP2_EB : MAG_PERSIST_SLEEP2);
@@ -184,7 +186,20 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
         }
         __builtin_amdgcn_s_sleep(1);
     }
-    done = __syncthreads_and(wave_ok ? 1 : 0) != 0; // also: s_rec complete
+    // every wave has everything?  One flag word per wave, ONE barrier (also: s_rec complete), one 32-byte read: the
+    // library's __syncthreads_and is three barriers around an LDS atomic.
+    {
+        constexpr int NWV = 8; // (512 threads; the 768-thread shape takes the library call)
+        if (blockDim.x == 64 * NWV) {
+            uint32_t *s_flag = (uint32_t *)(s_chunk + 4); // words 4 .. 7 of s_chunk: free (0, 1: best_param; 16 ..: stamps)
+            if ((tid & 63) == 0) s_flag[tid >> 6] = wave_ok ? 1u : 0u;
+            __syncthreads();
+            const uint4 f0 = ((const uint4 *)s_flag)[0], f1 = ((const uint4 *)s_flag)[1];
+            done = (f0.x & f0.y & f0.z & f0.w & f1.x & f1.y & f1.z & f1.w) != 0u;
+        } else {
+            done = __syncthreads_and(wave_ok ? 1 : 0) != 0;
+        }
+    }
 #ifdef MAG_PERSIST_STAMPS
     if (stamp) {
         stamp[1] = __builtin_amdgcn_s_memrealtime();
@@ -234,8 +249,13 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
     if (tid < 256) {
         const int c = tid >> 6, lane = tid & 63;
         const double *rec = (const double *)s_rec; // record m: doubles 4 m .. 4 m + 3
+        // (grid <= 256: at most four records per lane -- their loads in flight together, the additions in the loop's order)
+        double v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = lane + 64 * k < grid ? rec[4 * (lane + 64 * k) + c] : 0.0;
         double S = 0.0;
-        for (int m = lane; m < grid; m += 64) S += rec[4 * m + c];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) S = lane + 64 * k < grid ? S + v[k] : S;
         S = wave_sum_dpp(S);
         if (lane == 0) s_S[c] = S;
     }
@@ -593,12 +613,36 @@ __device__ inline void persist_block_sum(double (&acc)[4], double *s_red)
         for (int c = 0; c < 4; ++c) s_red[c * (kPersistThreads / 64) + (threadIdx.x >> 6)] = acc[c];
     }
     __syncthreads();
-    if (threadIdx.x < 2) {
+    constexpr int NWV = kPersistThreads / 64;
+    if (NWV == 8) {
+        // The eight waves' partials of each sum, added in wave order from 0.0 -- by wave 0 as a chain ACROSS LANES: lane
+        // 8 c + i loads partial (c, i) (one coalesced LDS read) and step k hands the running sum from lane i = k - 1 to lane
+        // i = k (row_shr:1) -- seven dependent adds.  The two publishing threads used to add the 32 values themselves, and
+        // with every register of the edge-block kernel taken the compiler fed them one LDS load at a time: twelve exposed
+        // LDS round trips (~0.5 us) between the workgroup's barrier and the publication of its record, every iteration.
+        // Same order of additions, same bits.
+        if (threadIdx.x < 64) {
+            const int l = threadIdx.x;
+            const double v = l < 4 * NWV ? s_red[l] : 0.0;
+            double t = 0.0 + v;
+#pragma unroll
+            for (int k = 1; k < NWV; ++k) {
+                const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(t), 0x111, 0xf, 0xf, false); // row_shr:1
+                const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(t), 0x111, 0xf, 0xf, false);
+                const double prev = __hiloint2double(hi, lo);
+                if ((l & (NWV - 1)) == k) t = prev + v;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                acc[c] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t), c * NWV + NWV - 1),
+                                          __builtin_amdgcn_readlane(__double2loint(t), c * NWV + NWV - 1));
+        }
+    } else if (threadIdx.x < 2) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             double t = 0.0;
 #pragma unroll
-            for (int i = 0; i < kPersistThreads / 64; ++i) t += s_red[c * (kPersistThreads / 64) + i];
+            for (int i = 0; i < NWV; ++i) t += s_red[c * NWV + i];
             acc[c] = t;
         }
     }
@@ -1017,6 +1061,10 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             target = uniform_f64(P.stop_mode == 2 ? P.tol * sqrt(bb) : P.tol);
         }
         const double rr = S0;
+        // alpha and beta before the stop test: their two division chains (~300 cycles, every wave, every iteration) then run
+        // alongside the square root of the cost instead of behind it; on the way out they are simply not used
+        const double alpha = uniform_f64(rr / S1);
+        const double beta = uniform_f64((rr + 2.0 * alpha * S2 + alpha * alpha * S3) / rr);
         cost = uniform_f64(P.stop_mode == 1 ? fabs(rr) : sqrt(rr));
         const long long it_done = j - 1;
         if (reporter && it_done >= 1 && it_done - 1 < P.hist_len) P.hist[it_done - 1] = cost;
@@ -1033,8 +1081,6 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         else if (!(fabs(rr) <= 1.79769313486231570e308)) verdict = 3;
         else if (it_done >= P.max_iter) verdict = 2;
         if (verdict) break;
-        const double alpha = uniform_f64(rr / S1);
-        const double beta = uniform_f64((rr + 2.0 * alpha * S2 + alpha * alpha * S3) / rr);
 
         // x += alpha p is the one update nothing in the iteration waits for.  It is done in the idle time before the first
         // sweep of the exchange, from what is on the chip by then: alpha p_{j-1} = (alpha / beta) (p_j + r_j) (p_j = -r_j +
