@@ -89,18 +89,21 @@ __device__ inline bool get_granules(const unsigned long long *base, uint32_t byt
 // (row_bcast:31): the total is in lane 63 and comes back in every lane.  A fixed order, like every sum here.
 __device__ inline double wave_sum_dpp(double v)
 {
-#define MAG_DPP_STEP(CTRL, ROWMASK)                                                                                  \
+// (BOUND: lanes without a source read 0 by the instruction itself -- with every row enabled the destination then needs no
+// zero written into it first, a third of the instructions of a shift step; the broadcast steps enable only some rows and keep
+// the explicit 0 for the others)
+#define MAG_DPP_STEP(CTRL, ROWMASK, BOUND)                                                                           \
     {                                                                                                                  \
-        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, false);                   \
-        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, false);                   \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, BOUND);                   \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, BOUND);                   \
         v += __hiloint2double(hi, lo);                                                                                 \
     }
-    MAG_DPP_STEP(0x111, 0xf) // row_shr:1
-    MAG_DPP_STEP(0x112, 0xf) // row_shr:2
-    MAG_DPP_STEP(0x114, 0xf) // row_shr:4
-    MAG_DPP_STEP(0x118, 0xf) // row_shr:8
-    MAG_DPP_STEP(0x142, 0xa) // row_bcast:15 into rows 1 and 3
-    MAG_DPP_STEP(0x143, 0xc) // row_bcast:31 into rows 2 and 3
+    MAG_DPP_STEP(0x111, 0xf, true)  // row_shr:1
+    MAG_DPP_STEP(0x112, 0xf, true)  // row_shr:2
+    MAG_DPP_STEP(0x114, 0xf, true)  // row_shr:4
+    MAG_DPP_STEP(0x118, 0xf, true)  // row_shr:8
+    MAG_DPP_STEP(0x142, 0xa, false) // row_bcast:15 into rows 1 and 3
+    MAG_DPP_STEP(0x143, 0xc, false) // row_bcast:31 into rows 2 and 3
 #undef MAG_DPP_STEP
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63),
                             __builtin_amdgcn_readlane(__double2loint(v), 63));
