@@ -1031,6 +1031,10 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
     // update, the dots and the deferred x update and written in the update -- two LDS operations per node and iteration
     // instead of four.
     constexpr bool QL = EB;
+    bool all_live = true; // every node slot of this workgroup carries a live tile (a scalar)
+#pragma unroll
+    for (int s = 0; s < NPT; ++s) all_live = all_live && (flags[s] & 8) != 0;
+    all_live = __builtin_amdgcn_readfirstlane(__syncthreads_and(all_live ? 1 : 0)) != 0;
     double target = P.tol, bb = 0.0;
     long long j = 0;
     int verdict = 0; // 1 converged, 2 iteration cap, 3 non-finite
@@ -1091,25 +1095,41 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         // a few ulps per step.  beta = 0 (an exactly zero residual) cannot be divided by: then, and only then, here.
         const bool xnow = !(beta != 0.0) || !(fabs(beta) <= 1.79769313486231570e308);
         // ---- vector updates: r in registers, p and x in LDS, halo copies in LDS (their q from the publishers)
+        if (!kPersistDeferX || xnow) { // x += alpha p here, on the critical path, only when it cannot be rebuilt later
 #pragma unroll
-        for (int s = 0; s < NPT; ++s) {
-            if (!(flags[s] & 8)) continue;
-            const int lt = t_lt(s);
-            double2 *xy = t_xy(s), *pim = xy + cap, *hr = pim + cap, *xs = hr + maxh;
-            const double2 po = pim[lt];
-            double2 pn;
-            if (!kPersistDeferX || xnow) { // x += alpha p here, on the critical path, only when it cannot be rebuilt later
+            for (int s = 0; s < NPT; ++s) {
+                if (!(flags[s] & 8)) continue;
+                const int lt = t_lt(s);
+                double2 *xy = t_xy(s), *pim = xy + cap, *xs = pim + cap + maxh;
+                const double2 po = pim[lt];
                 double2 xo = xs[lt];
                 xo.x += alpha * po.x;
                 xo.y += alpha * po.y;
                 xs[lt] = xo;
             }
+        }
+        auto update_slot = [&](int s) {
+            const int lt = t_lt(s);
+            double2 *xy = t_xy(s), *pim = xy + cap;
+            const double2 po = pim[lt];
             const double2 qv = QL ? xy[lt] : q[s];
+            double2 pn;
             r[s].x += alpha * qv.x;
             r[s].y += alpha * qv.y;
             pn.x = -r[s].x + beta * po.x;
             pn.y = -r[s].y + beta * po.y;
             pim[lt] = pn;
+        };
+        // A workgroup whose node slots are all live (every one on the 1M mesh but the last) runs them as ONE basic block: the
+        // eight LDS loads of the four slots go out together.  With a test per slot each slot waited for its own two loads
+        // before the next slot's were issued.  (A dead slot's LDS is never read by anybody else: it is skipped, not zeroed.)
+        if (all_live) {
+#pragma unroll
+            for (int s = 0; s < NPT; ++s) update_slot(s);
+        } else {
+#pragma unroll
+            for (int s = 0; s < NPT; ++s)
+                if (flags[s] & 8) update_slot(s);
         }
 #pragma unroll
         for (int e = 0; e < NH; ++e)
@@ -1203,9 +1223,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
                          tid == 0 ? make_double2(acc[0], acc[1]) : make_double2(acc[2], acc[3]));
         if (kPersistDeferX && !xnow) { // the deferred x += alpha p_{j-1}, in the shadow of the exchange's first wait
             const double ab = uniform_f64(alpha / beta);
-#pragma unroll
-            for (int s = 0; s < NPT; ++s) {
-                if (!(flags[s] & 8)) continue;
+            auto x_slot = [&](int s) {
                 const int lt = t_lt(s);
                 double2 *xy = t_xy(s), *pim = xy + cap, *xs = pim + cap + maxh;
                 const double2 pj = pim[lt], rv = r[s];
@@ -1213,6 +1231,14 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
                 xo.x += ab * (pj.x + rv.x);
                 xo.y += ab * (pj.y + rv.y);
                 xs[lt] = xo;
+            };
+            if (all_live) {
+#pragma unroll
+                for (int s = 0; s < NPT; ++s) x_slot(s);
+            } else {
+#pragma unroll
+                for (int s = 0; s < NPT; ++s)
+                    if (flags[s] & 8) x_slot(s);
             }
         }
         MAG_STAMP(3) // workgroup sums (wave trees, barrier, eight waves in order) + record published
