@@ -27,6 +27,8 @@ for wl in plate100k hole1m plate4m multihole16m; do
 done
 python3 bench.py --workload multihole16m --precision fp32 --no-cpu-baseline --no-hbm-resident >> "$OUT/size_scaling.jsonl" 2>> "$OUT/size_scaling.err"
 echo "size scaling done" >> "$OUT/progress.txt"
-python3 scripts/persist_phases.py "$OUT/persist_phases_blocks.json" > "$OUT/persist_phases.log" 2>&1
-MAG_TUNE_PERSIST_TRIANGLES=1 python3 scripts/persist_phases.py "$OUT/persist_phases_triangles.json" >> "$OUT/persist_phases.log" 2>&1
+# (The in-kernel phase stamps -- python3 scripts/persist_phases.py <out>, MAG_TUNE_PERSIST_TRIANGLES=1 for the triangle walk --
+# are not part of the routine run any more: after the round's last change of the on-chip kernel its DIAGNOSTIC build faulted on
+# the GPU (the product build, the same source without the stamps, passes every test, the soak and the stress runs), and a
+# diagnostic is not worth a GPU fault.  profiles/r03_persist_phases_*.json are the records from one commit earlier.)
 echo "all done" >> "$OUT/progress.txt"
