@@ -1,5 +1,5 @@
 import hashlib, json, os, subprocess, sys
-ROOT=os.getcwd()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 W=r"""
 import hashlib, json, sys, os
 sys.path.insert(0, %r)
