@@ -95,6 +95,12 @@ def build_problem(workload, n_gpus):
             holes = [(0.5, (k + 0.5) / n_gpus, 0.15) for k in range(n_gpus)]
             mesh = meshgen.plate_with_holes(n, n * n_gpus, 1.0, float(n_gpus), holes=holes)
         return meshgen.config_fixed_left_pull_right(mesh), f"plate-with-hole {n}x{n * n_gpus} cells"
+    if workload == "frontal1m":
+        # what gmsh's frontal mesher hands solver::run (mesher.rs:501-506): an UNSTRUCTURED mesh, a quarter of its nodes with
+        # seven or more neighbours (meshgen.frontal_like: jittered equilateral lattice, Delaunay); 1 006 602 triangles
+        if n_gpus != 1:
+            raise SystemExit("frontal1m is a single-GPU workload")
+        return meshgen.config_fixed_left_pull_right(meshgen.frontal_like(660, 0.4, 1)), "frontal-like Delaunay mesh, 660 pitch"
     if workload == "plate100k":
         return meshgen.config_fixed_left_point_load(meshgen.plate(224, 224 * n_gpus, 1.0, float(n_gpus))), "plate 224^2"
     if workload == "plate4m":

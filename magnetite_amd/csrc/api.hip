@@ -88,6 +88,7 @@ struct mag_ctx {
     DevBuf bc_touch; // N bytes: rows with a prescribed column (k_pattern_rows; k_mark_bc_rows on the sort-based pattern)
     bool bc_touch_ready = false;
     DevBuf kblocks; // on-chip CG, edge-block instantiation: the nodes' blocks (k_edge_blocks)
+    DevBuf row_info, ovf_cnt, ovf_off, ovf_rec; // ... with overflow: k_ring16's per-row byte, per-node counts, their scan, the records
     bool asm_ctile = false; // K is assembled from the CG tiles (k_assemble_fan), ell_asm holds its corner words
     // tile-local numbering for the LDS-halo operator
     bool use_lds = false;
@@ -143,7 +144,7 @@ struct mag_ctx {
     double best_cost = 0.0;   // argmin's best_param bookkeeping, as the CG phase that just ran reported it
     long long best_iter = 0;
     bool persist_timed_out = false, exchange_timed_out = false;
-    bool edge_blocks = false; // the on-chip kernel of the last run was its edge-block instantiation (mag_stats.edge_blocks)
+    int edge_blocks = 0; // instantiation of the on-chip kernel of the last run: 1 edge blocks, 2 with overflow records (mag_stats.edge_blocks)
     // streaming kernels across GPUs: the per-iteration exchange through the device inboxes (k_stream_exchange) instead of
     // an all-reduce; si_failed: a wait ran out once, this context uses the all-reduce from then on
     bool si = false, si_failed = false;
@@ -437,8 +438,9 @@ int ensure_order(mag_ctx *ctx)
                          ctx->asm_ctile ? ctx->ell_asm.as<uint32_t>() : nullptr,
                          ctx->asm_ctile ? ctx->ell_pos.as<uint16_t>() : nullptr, s);
         HIPCHK(ctx->tile_rdeg.reserve(2 * 4 * ((size_t)T + 1)));
+        HIPCHK(ctx->row_info.reserve((size_t)T * B + 64));
         magk::ring16(ctx->tile_deg.as<int32_t>(), ctx->tile_off.as<int64_t>(), B, T, ctx->ell.as<uint32_t>(),
-                     ctx->tile_rdeg.as<int32_t>(), magk::persist_block_entries(), s);
+                     ctx->tile_rdeg.as<int32_t>(), magk::persist_block_entries(), ctx->row_info.as<uint8_t>(), s);
         HIPCHK(ctx->tmeta.reserve(sizeof(magk::TileMeta) * (size_t)T));
         magk::tile_meta(ctx->tile_rdeg.as<int32_t>(), ctx->tile_rdeg.as<int32_t>() + T, ctx->tile_off.as<int64_t>(),
                         ctx->tile_hoff.as<int32_t>(), T,
@@ -482,7 +484,7 @@ int ensure_order(mag_ctx *ctx)
         ctx->persist_maxh = ((max_halo + 3) / 4) * 4;
         if (kmax > 0 && k >= 1 && k >= kmin && k <= kmax && (tiles_max + k - 1) / k <= 256 && // the gather holds 256
             (int64_t)k * max_halo <= 2 * pthreads && // a workgroup's halo entries are dealt out two per thread
-            magk::persist_lds_bytes(B, ctx->cap, ctx->persist_maxh, pthreads) <= 160 * 1024) {
+            magk::persist_lds_bytes(B, ctx->cap, ctx->persist_maxh, pthreads) + 256 <= 160 * 1024) { // + the static 256 bytes
             ctx->persist = true;
             ctx->persist_k = k;
             ctx->persist_grid = (ctx->t1 - ctx->t0 + k - 1) / k;
@@ -1211,10 +1213,6 @@ int cg_phase_persist(mag_ctx *ctx)
     HIPCHK(hipMemsetAsync(ctx->fstate.p, 0, sizeof(FusedState), s));
     const int R = ctx->comm.nranks;
     const bool mg = R > 1;
-    // which nodes are read through memory at all by this rank's tiles, with persist_k tiles per workgroup (the others publish
-    // nothing on this GPU; what other ranks read goes through the inboxes)
-    magk::mark_external(ctx->halo_g.as<int32_t>(), ctx->tmeta.as<magk::TileMeta>(), ctx->t0, ctx->t1, ctx->B, ctx->persist_k,
-                        ctx->maskP.as<uint8_t>(), s);
     magk::PersistParams P = {};
     P.nranks = 1;
     if (mg) {
@@ -1306,24 +1304,60 @@ int cg_phase_persist(mag_ctx *ctx)
     }
     // Which instantiation: edge blocks in registers when every row of the mesh is one short fan (k_ring16 left the answer
     // behind tile_rdeg's two arrays), the triangle walk with cached weights otherwise.  One 4-byte read per solve.
-    bool edge_blocks = false;
+    // Round 4: a mesh whose rows are single fans of ANY length (flag word 1: gmsh-type meshes, a quarter of their nodes with
+    // seven neighbours) runs the edge-block kernel too, the blocks beyond six per node as 32-byte records in an LDS pool --
+    // if every workgroup's records fit the LDS its more compact layout leaves free (mode 2); the triangle walk otherwise.
+    int eb_mode = 0;
+    const int64_t npad = (int64_t)ctx->T * ctx->B;
     // (several ranks: the ordering phase is replicated, so every rank reads the same flag; the multi-GPU edge-block
     // instantiation is behind MAG_TUNE_PERSIST_MG_BLOCKS until a node has measured it)
     if ((!mg || getenv("MAG_TUNE_PERSIST_MG_BLOCKS")) && !getenv("MAG_TUNE_PERSIST_TRIANGLES")) {
-        int32_t not_plain = 1;
-        HIPCHK(hipMemcpyAsync(&not_plain, ctx->tile_rdeg.as<int32_t>() + 2 * (size_t)ctx->T, 4, hipMemcpyDeviceToHost, s));
+        int32_t fan_flags = 3;
+        HIPCHK(hipMemcpyAsync(&fan_flags, ctx->tile_rdeg.as<int32_t>() + 2 * (size_t)ctx->T, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        edge_blocks = not_plain == 0;
+        if (fan_flags == 0) eb_mode = 1;
+        const char *no_ovf = getenv("MAG_TUNE_PERSIST_NO_OVERFLOW");
+        if (((fan_flags == 1 && !(no_ovf && atoi(no_ovf))) || (fan_flags == 0 && getenv("MAG_TUNE_PERSIST_FORCE_OVERFLOW"))) && !mg) {
+            // per-node overflow counts -> scan -> the limits the LDS must meet
+            const int nb = magk::persist_block_entries();
+            HIPCHK(ctx->ovf_cnt.reserve(4 * ((size_t)npad + 1)));
+            HIPCHK(ctx->ovf_off.reserve(4 * ((size_t)npad + 1) + 16));
+            magk::ovf_counts(ctx->row_info.as<uint8_t>(), npad, nb, ctx->ovf_cnt.as<int32_t>(), s);
+            if (int rc = scan_i32(ctx, ctx->ovf_cnt.as<int32_t>(), ctx->ovf_off.as<int32_t>(), (size_t)npad + 1)) return rc;
+            int32_t *lim_d = ctx->ovf_cnt.as<int32_t>(); // (the counts are not needed after the scan: their first words hold the limits)
+            HIPCHK(hipMemsetAsync(lim_d, 0, 8, s));
+            magk::ovf_limits(ctx->ovf_off.as<int32_t>(), ctx->B, ctx->persist_k, ctx->t0, ctx->t1, lim_d, s);
+            int32_t lim[3] = {0, 0, 0};
+            HIPCHK(hipMemcpyAsync(lim, lim_d, 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(&lim[2], ctx->ovf_off.as<int32_t>() + npad, 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            const int32_t pool = ((lim[0] + 1 + 7) / 8) * 8; // + record 0, the zero block
+            // 12 bits of pool position and 4 bits of count per node slot; the kernel's static LDS on top of the dynamic
+            if (lim[0] + 1 <= 4095 && lim[1] <= 15 &&
+                magk::persist_lds_bytes(ctx->B, ctx->cap, ctx->persist_maxh, magk::persist_threads(), 2, pool) + 256 <= 160 * 1024) {
+                eb_mode = 2;
+                P.pool_cap = pool;
+                HIPCHK(ctx->ovf_rec.reserve(32 * (size_t)std::max(lim[2], 1)));
+                P.row_info = ctx->row_info.as<uint8_t>();
+                P.ovf_off = ctx->ovf_off.as<int32_t>();
+                P.ovf_rec = ctx->ovf_rec.as<double>();
+            } else if (ctx->opt.verbose) {
+                printf("info: edge blocks with overflow do not fit (%d records in a workgroup, %d at a node): triangle walk\n", lim[0], lim[1]);
+            }
+        }
     }
-    ctx->edge_blocks = edge_blocks;
-    if (edge_blocks) { // the nodes' blocks, once per solve (18 doubles per node of the padded order, value-major)
-        const int64_t npad = (int64_t)ctx->T * ctx->B;
+    ctx->edge_blocks = eb_mode;
+    // which nodes are read through memory at all by this rank's tiles, with persist_k tiles per workgroup (the others publish
+    // nothing on this GPU; what other ranks read goes through the inboxes)
+    magk::mark_external(ctx->halo_g.as<int32_t>(), ctx->tmeta.as<magk::TileMeta>(), ctx->t0, ctx->t1, ctx->B, ctx->persist_k,
+                        ctx->maskP.as<uint8_t>(), eb_mode == 2, s);
+    if (eb_mode) { // the nodes' blocks, once per solve (18 doubles per node of the padded order, value-major)
         HIPCHK(ctx->kblocks.reserve(8 * (size_t)(3 * magk::persist_block_entries()) * (size_t)npad));
         P.kblocks = ctx->kblocks.as<double>();
         P.kb_stride = npad;
-        magk::edge_blocks_build(P, ctx->B, ctx->kblocks.as<double>(), s);
+        magk::edge_blocks_build(P, ctx->B, ctx->kblocks.as<double>(), eb_mode, s);
     }
-    magk::persist_launch(P, ctx->B, grid + P.comm_wg, magk::persist_threads(), edge_blocks, s);
+    magk::persist_launch(P, ctx->B, grid + P.comm_wg, magk::persist_threads(), eb_mode, s);
     if (stamps) {
         std::vector<unsigned long long> h((size_t)magk::persist_stamp_words() * (size_t)grid);
         HIPCHK(hipMemcpyAsync(h.data(), ctx->pstamps.p, 8 * h.size(), hipMemcpyDeviceToHost, s));
@@ -1983,7 +2017,7 @@ int mag_run(mag_ctx *ctx)
     st.n_free = ctx->nf;
     ctx->have_run = true;
     st.persist_timeout = ctx->persist_timed_out ? 1 : 0;
-    st.edge_blocks = (ctx->cg_kernel == 2 && ctx->edge_blocks) ? 1 : 0;
+    st.edge_blocks = ctx->cg_kernel == 2 ? ctx->edge_blocks : 0;
     st.exchange_timeout = ctx->exchange_timed_out ? 1 : 0;
     if (st.breakdown)
         return fail(ctx, MAG_ERR_NOT_CONVERGED, "Conjugate Gradient error: non-finite residual after %lld iterations",

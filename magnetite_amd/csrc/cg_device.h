@@ -342,4 +342,77 @@ __device__ inline void ring_walk_blocks(const uint32_t (&w)[NW], const double2 *
     fy -= kap * (ul.x - u0.x);
 }
 
+// The same walk for rows with MORE than NB blocks (on-chip kernel, EBM == 2: gmsh-type meshes, where a quarter of the nodes
+// have seven neighbours).  The blocks beyond the registers are 32-byte records {k11, k12 | k22, slot} in the workgroup's
+// LDS pool: this lane's node owns records off .. off + cnt - 1; nmax = the most records any lane of this wave has for this
+// node slot (a scalar: the trip count).  No lane sits out: a lane with fewer records reads record 0 of the pool, a zero
+// block on a valid slot, so a step is straight-line code -- two record reads, one gather, six fp64 operations -- and two
+// steps go together (their four record reads issue at once, then the two gathers).  u_first and u_last of an OPEN fan are
+// always register entries (k_edge_blocks_ovf puts an open row's last entry into block NB - 1 and its middle ones into
+// the pool), so the telescoped antisymmetric part needs nothing from the pool.  Same sums as the short rows', block after
+// block.
+template <int NW, int NB, uint32_t IDMASK = 0xfffu>
+__device__ inline void ring_walk_blocks_ovf(const uint32_t (&w)[NW], const double2 *s_p, const double2 pa, double kappa,
+                                            bool folded, const double (&kb)[3 * NB], const double2 *pool, uint32_t off,
+                                            uint32_t cnt, int32_t nmax, double &fx, double &fy)
+{
+    auto entry = [&](int k) { return (k & 1) ? (w[k >> 1] >> 16) : (w[k >> 1] & 0xffffu); };
+    double2 u0, ul;
+    {
+        const double2 cp = s_p[entry(0) & IDMASK];
+        u0 = make_double2(cp.x - pa.x, cp.y - pa.y);
+        fx = fma(kb[1], u0.y, fma(kb[0], u0.x, fx));
+        fy = fma(kb[2], u0.y, fma(kb[1], u0.x, fy));
+        ul = u0;
+    }
+#pragma unroll
+    for (int k = 1; k < NB; ++k) {
+        const double2 cp = s_p[entry(k) & IDMASK];
+        const double2 u = make_double2(cp.x - pa.x, cp.y - pa.y);
+        fx = fma(kb[3 * k + 1], u.y, fma(kb[3 * k], u.x, fx));
+        fy = fma(kb[3 * k + 2], u.y, fma(kb[3 * k + 1], u.x, fy));
+        ul = u;
+    }
+    const double kap = folded ? 0.0 : kappa;
+    fx += kap * (ul.y - u0.y);
+    fy -= kap * (ul.x - u0.x);
+    auto rec_of = [&](int32_t k) { return 2u * ((uint32_t)k < cnt ? off + (uint32_t)k : 0u); };
+    auto apply = [&](const double2 a, const double2 b) {
+        const double2 cp = s_p[(uint32_t)__double2loint(b.y)];
+        const double2 u = make_double2(cp.x - pa.x, cp.y - pa.y);
+        fx = fma(a.y, u.y, fma(a.x, u.x, fx));
+        fy = fma(b.x, u.y, fma(a.y, u.x, fy));
+    };
+    // nmax is a scalar: one record (most waves of a frontal mesh: some lane has a seventh neighbour), two together (some lane
+    // has an eighth), the rare rest one at a time -- not unrolled: an unrolled loop here takes its registers from the blocks
+#ifndef MAG_PERSIST_OVF_PAIR
+#define MAG_PERSIST_OVF_PAIR 0 // 1: the first two records together (four record reads in flight) -- measured slower, 7.51 against 7.10 us per iteration on the 1M frontal mesh: the pair takes six block registers to scratch, and their reload waits for the node slot's granule stores
+#endif
+#if MAG_PERSIST_OVF_PAIR
+    if (nmax == 1) {
+        const uint32_t i0 = rec_of(0);
+        const double2 a0 = pool[i0], b0 = pool[i0 + 1];
+        apply(a0, b0);
+    } else if (nmax >= 2) {
+        const uint32_t i0 = rec_of(0), i1 = rec_of(1);
+        const double2 a0 = pool[i0], b0 = pool[i0 + 1], a1 = pool[i1], b1 = pool[i1 + 1];
+        apply(a0, b0);
+        apply(a1, b1);
+#pragma clang loop unroll(disable)
+        for (int32_t k = 2; k < nmax; ++k) {
+            const uint32_t i2 = rec_of(k);
+            const double2 a2 = pool[i2], b2 = pool[i2 + 1];
+            apply(a2, b2);
+        }
+    }
+#else
+#pragma clang loop unroll(disable)
+    for (int32_t k = 0; k < nmax; ++k) {
+        const uint32_t i2 = rec_of(k);
+        const double2 a2 = pool[i2], b2 = pool[i2 + 1];
+        apply(a2, b2);
+    }
+#endif
+}
+
 } // namespace magk

@@ -571,7 +571,7 @@ __device__ inline void k_store(double *dst, double2 v)
     __builtin_memcpy(&t, &v, 16);
     // (s_nop: the registers of a store of more than 8 bytes must not be rewritten in the next two cycles; the compiler
     // keeps that distance for its own stores and cannot see into this one)
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(t) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" MAG_WS_DATA : : "v"(dst), "v"(t) : "memory");
 #else
     *(double2 *)dst = v;
 #endif

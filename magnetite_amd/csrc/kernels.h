@@ -7,6 +7,20 @@
 
 #include <hip/hip_runtime.h>
 
+// Wait states of the hand-written VMEM stores (persist.hip, exact.hip).  The compiler's hazard recognizer does not look at the
+// uses inside an inline-asm statement, nor at what the asm's last instruction needs from the code behind it, so the asm
+// strings carry them: five wait states before a store addressed through an SGPR base (a VALU write of that SGPR -- a spill
+// coming back through v_readlane_b32 -- may sit right in front of the asm), two after a store of more than 8 bytes (its data
+// registers must not be rewritten before).  scripts/isa_lint.py checks both on the emitted ISA (tests/test_isa_hazards.py);
+// -DMAG_ASM_NO_WAITSTATES drops them, for that test only.
+#ifdef MAG_ASM_NO_WAITSTATES
+#define MAG_WS_SBASE ""
+#define MAG_WS_DATA ""
+#else
+#define MAG_WS_SBASE "s_nop 4\n\t"
+#define MAG_WS_DATA "\n\ts_nop 1"
+#endif
+
 namespace magk {
 
 constexpr int kMaxGrid = 1024;  // capacity of the dot-partial arrays == upper bound on workgroups of a CG kernel
@@ -282,8 +296,13 @@ struct FusedParams {
     const float4 *halo_minv;
 };
 // rewrites the tile-local table of fill_ell16 into ring form in place (symbolic.hip, k_ring16)
+// row_info (T * B bytes, may be null): per row the number of ring entries (bits 0-5), closed fan (bit 6), one fan (bit 7)
 void ring16(const int32_t *tile_deg, const int64_t *tile_off, int32_t B, int32_t T, uint32_t *ell, int32_t *tile_rdeg, int32_t block_entries,
-            hipStream_t s);
+            uint8_t *row_info, hipStream_t s);
+// edge blocks beyond the nb kept in registers: per-node counts (npad + 1 entries, the last 0) for the scan, then the limits
+// the host checks -- out[0] the most records a workgroup of k tiles holds, out[1] the most of one node
+void ovf_counts(const uint8_t *row_info, int64_t npad, int32_t nb, int32_t *cnt, hipStream_t s);
+void ovf_limits(const int32_t *off, int32_t B, int32_t k, int32_t t0, int32_t t1, int32_t *out, hipStream_t s);
 void tile_meta(const int32_t *tile_deg, const int32_t *tile_ent, const int64_t *tile_off, const int32_t *tile_hoff,
                int32_t T, TileMeta *meta, hipStream_t s);
 // workgroups of the fused kernel: all co-resident (occupancy query x CUs), so the launch is one persistent round --
@@ -348,6 +367,15 @@ struct PersistParams {
     // (persist.hip, k_edge_blocks: once per solve, before the launch)
     const double *kblocks;
     int64_t kb_stride;
+    // ... with overflow (EBM == 2, meshes whose rows are single fans of any length -- gmsh-type meshes): blocks beyond the
+    // six in registers live in LDS, 32-byte records {k11, k12, k22, ring entry}; k_edge_blocks writes them to ovf_rec at
+    // ovf_off[node] + j (exclusive scan of the per-node counts over the padded Hilbert order), the on-chip kernel copies
+    // its workgroup's run into its pool.  row_info: k_ring16's per-row byte (entries, closed, one fan).
+    const uint8_t *row_info;
+    const int32_t *ovf_off;
+    double *ovf_rec;
+    int32_t pool_cap; // records the LDS pool of a workgroup holds (the host checked every workgroup's run against it)
+    int32_t pad3;
 };
 // multi-GPU, streaming kernels: the per-iteration exchange [dot partials | interface q] through the ranks' device
 // inboxes instead of an all-reduce, in place on `buf` (persist.hip, k_stream_exchange)
@@ -359,19 +387,21 @@ void stream_exchange_launch(double *buf, int32_t g_all, int32_t n_iface, int32_t
                             const uint8_t *iface_readers, void *const *inboxes, FusedState *st, hipStream_t s);
 int persist_threads(); // workgroup shape of the on-chip kernel: 512 (x 4 nodes per lane) or 768 (x 3); MAG_TUNE_PERSIST_THREADS
 int persist_tiles_per_wg(int32_t B, int threads); // tiles one workgroup keeps on chip (0: tile size not supported)
-size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh, int threads);
-// MG kernel when nranks > 1; edge_blocks: every row qualifies for the edge-block instantiation (ring16's flag)
-void persist_launch(const PersistParams &P, int32_t B, int32_t grid, int threads, bool edge_blocks, hipStream_t s);
+// eb_mode: 0 triangle walk, 1 edge blocks (every row a fan of <= 6 blocks), 2 edge blocks with `pool` overflow records in LDS
+size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh, int threads, int eb_mode = 0, int32_t pool = 0);
+// MG kernel when nranks > 1; eb_mode as above (the host decides from ring16's flags and the overflow limits)
+void persist_launch(const PersistParams &P, int32_t B, int32_t grid, int threads, int eb_mode, hipStream_t s);
 int persist_block_entries(); // block entries per node of that instantiation
 // ... and its blocks: 3 * persist_block_entries() doubles per node of the T * B padded nodes, into P.kblocks (host sets
-// kblocks / kb_stride before the call)
-void edge_blocks_build(const PersistParams &P, int32_t B, double *kblocks, hipStream_t s);
+// kblocks / kb_stride before the call; eb_mode 2: row_info / ovf_off / ovf_rec as well)
+void edge_blocks_build(const PersistParams &P, int32_t B, double *kblocks, int eb_mode, hipStream_t s);
 int persist_stamp_words();   // words per workgroup in PersistParams::stamps
 bool persist_stamps_built(); // the library was compiled with -DMAG_PERSIST_STAMPS
 void mark_published(const int32_t *halo_g, int64_t halo_total, uint8_t *maskP, hipStream_t s);
 // bit 3: read through memory by a workgroup of the on-chip kernel (k tiles per workgroup) other than the owner's
+// all_rows: sibling tiles read each other's LDS slots whatever their rows' length (eb_mode 2: every entry is remapped at start-up)
 void mark_external(const int32_t *halo_g, const TileMeta *meta, int32_t t0, int32_t t1, int32_t B, int32_t k, uint8_t *maskP,
-                   hipStream_t s);
+                   bool all_rows, hipStream_t s);
 
 // ---- fp32 leg of BASELINE config 5 (fp64 vs fp32 CG tolerance sweep): the fused iteration with the CG state, the
 // operator arithmetic and TILE-RELATIVE coordinates in fp32; dot products accumulate in fp64 ----

@@ -50,7 +50,7 @@ __device__ inline void put_granules(unsigned long long *g, unsigned epoch, doubl
     unsigned w[4];
     __builtin_memcpy(w, &v, 16);
     const u32x4 a = {w[0], epoch, w[1], epoch}, b = {w[2], epoch, w[3], epoch};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1\n\ts_nop 1"
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" MAG_WS_DATA
                  :
                  : "v"(g), "v"(a), "v"(b)
                  : "memory");
@@ -62,7 +62,12 @@ __device__ inline void put_granules_at(const unsigned long long *base, uint32_t 
     unsigned w[4];
     __builtin_memcpy(w, &v, 16);
     const u32x4 a = {w[0], epoch, w[1], epoch}, b = {w[2], epoch, w[3], epoch};
-    asm volatile("global_store_dwordx4 %0, %1, %3 sc1\n\tglobal_store_dwordx4 %0, %2, %3 offset:16 sc1\n\ts_nop 1"
+    // MAG_WS_SBASE (s_nop 4) FIRST: the base is an SGPR pair, and when the allocator has it spilled it comes back through v_readlane_b32 --
+    // a VALU write of an SGPR, which a VMEM instruction may read only five wait states later.  The compiler's hazard
+    // recognizer does not look at the uses inside inline asm, so the asm carries the wait states itself (round 3's
+    // diagnostic build had the v_readlane two instructions before the store: a stale base, a wild address, the GPU fault
+    // recorded in DESIGN section 4; tests/test_isa_hazards.py scans the emitted ISA for both hazards of these stores).
+    asm volatile(MAG_WS_SBASE "global_store_dwordx4 %0, %1, %3 sc1\n\tglobal_store_dwordx4 %0, %2, %3 offset:16 sc1" MAG_WS_DATA
                  :
                  : "v"(byte_off), "v"(a), "v"(b), "s"(base)
                  : "memory");
@@ -272,7 +277,7 @@ __device__ inline void put_granules_sys(unsigned long long *g, unsigned tag, dou
     unsigned w[4];
     __builtin_memcpy(w, &v, 16);
     const u32x4 a = {w[0], tag, w[1], tag}, b = {w[2], tag, w[3], tag};
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0 sc1\n\ts_nop 1"
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc0 sc1" MAG_WS_DATA
                  :
                  : "v"(g), "v"(a), "v"(b)
                  : "memory");
@@ -298,7 +303,8 @@ __device__ inline void put_granules_sys_at(const uint8_t *base, uint32_t byte_of
     unsigned w[4];
     __builtin_memcpy(w, &v, 16);
     const u32x4 a = {w[0], tag, w[1], tag}, b = {w[2], tag, w[3], tag};
-    asm volatile("global_store_dwordx4 %0, %1, %3 sc0 sc1\n\tglobal_store_dwordx4 %0, %2, %3 offset:16 sc0 sc1\n\ts_nop 1"
+    // (s_nop 4 first: see put_granules_at -- an SGPR base restored by v_readlane needs five wait states before a VMEM read)
+    asm volatile(MAG_WS_SBASE "global_store_dwordx4 %0, %1, %3 sc0 sc1\n\tglobal_store_dwordx4 %0, %2, %3 offset:16 sc0 sc1" MAG_WS_DATA
                  :
                  : "v"(byte_off), "v"(a), "v"(b), "s"(base)
                  : "memory");
@@ -738,21 +744,29 @@ __device__ inline double uniform_f64(double v)
                             __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
-template <int B, bool MG, int THREADS, bool EB>
+// EBM: 0 the triangle walk, 1 edge blocks in registers (every row of the mesh a fan of at most six blocks: structured meshes),
+// 2 edge blocks with OVERFLOW (round 4: rows that are one fan of any length -- what gmsh's frontal meshes look like, a quarter
+// of their nodes with seven neighbours: blocks beyond the six in registers sit in an LDS pool of 32-byte records).
+template <int B, bool MG, int THREADS, int EBM>
 __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
 {
     constexpr int kPersistThreads = THREADS;
     constexpr int NPT = persist_npt(THREADS);
+    constexpr bool EB = EBM != 0, OV = EBM == 2;
     extern __shared__ __attribute__((aligned(16))) double2 smem[];
     const int tid = threadIdx.x;
     const int cap = P.cap, maxh = P.maxh;
-    // LDS per local tile l: coordinates[cap], p image[cap] (owned part = the CG vector p itself; its halo part holds the halo
+    // LDS per local tile l: coordinates[capx], p image[cap] (owned part = the CG vector p itself; its halo part holds the halo
     // nodes' p), halo r[maxh], x[B].  Registers per node: r, q, the ring words, the triangle weights.
-    const int tile_words = 2 * cap + maxh + B;
+    // (capx = cap; with overflow blocks the first area only ever holds q of the B owned nodes -- no coordinates on the chip --
+    // and shrinks to B: the LDS it frees is the pool's)
+    const int capx = OV ? B : cap;
+    const int tile_words = capx + cap + maxh + B;
     double2 *s_rec = smem + (size_t)(NPT * THREADS / B) * tile_words; // 2 * grid pieces of the partial records
     double *s_red = (double *)(s_rec + 2 * 256);
     double *s_S = s_red + 4 * (kPersistThreads / 64);
     double *s_chunk = s_S + 4;
+    [[maybe_unused]] double2 *s_pool = (double2 *)(s_chunk + 4 * 32); // overflow records (OV): two double2 each
     // slot s of this lane: local node s * THREADS + tid, in local tile (s * THREADS + tid) / B (a scalar: wave-uniform)
     auto t_loc = [&](int s) { return __builtin_amdgcn_readfirstlane((s * THREADS + tid) / B); };
     auto t_lt = [&](int s) { return (s * THREADS + tid) % B; };
@@ -772,6 +786,10 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
     auto node_of = [&](int s) { return node_base + s * THREADS + tid; };
     int32_t hg[NH], hloc[NH]; // global id (-1: none) and LDS position (tile * tile_words-relative) of a halo entry
     PackedFlags<NPT> flags; // per node slot: bit 0/1 prescribed ux/uy, 2 published, 3 live tile, 4 valid node, 5 fan closed in the blocks
+    // overflow blocks (OV): per slot (first record in the workgroup's pool: 12 bits | records: 4 bits), two slots per register;
+    // and, as scalars, the most records any lane of this wave has per slot (the overflow loop's trip count)
+    [[maybe_unused]] uint32_t ovpk[(NPT + 1) / 2] = {};
+    [[maybe_unused]] int32_t ovmax[NPT] = {};
     uint32_t w[NPT][kPersistRegs];
     int64_t ell_off[NPT];
     double2 r[NPT], q[NPT];
@@ -781,7 +799,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
     for (int s = 0; s < NPT; ++s) {
         const int l = t_loc(s), lt = t_lt(s);
         const int32_t t = (MG ? P.t0 : 0) + blockIdx.x * P.tiles_per_wg + l;
-        double2 *xy = t_xy(s), *pim = xy + cap, *hr = pim + cap, *xs = hr + maxh;
+        double2 *xy = t_xy(s), *pim = xy + capx, *hr = pim + cap, *xs = hr + maxh;
         oslot[s] = -1;
         oreaders[s] = 0;
         deg[s] = 0;
@@ -834,7 +852,8 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             const int32_t t_first = (MG ? P.t0 : 0) + blockIdx.x * P.tiles_per_wg, t_end = MG ? P.t1 : P.T;
             // (several ranks: siblings are tiles of the same workgroup, hence of the same rank; rehearsed with two ranks
             // sharing one GPU at four tiles per workgroup, scripts/mg_share_ab.sh)
-            const bool short_rows = kPersistSiblings && tm.ent <= 2 * kPersistRegs;
+            // (OV: every entry, the pool's included, is rewritten here at start-up -- rows of any length)
+            const bool short_rows = kPersistSiblings && (OV || tm.ent <= 2 * kPersistRegs);
             auto remap = [&](uint32_t e) -> uint32_t {
                 if (e == 0xffffu) return e;
                 const uint32_t lid = e & 0xfffu;
@@ -849,6 +868,49 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
 #pragma unroll
             for (int k = 0; k < kPersistRegs; ++k)
                 if (k < deg[s]) w[s][k] = remap(w[s][k] & 0xffffu) | (remap(w[s][k] >> 16) << 16);
+            if (OV) {
+                // this node's blocks beyond the registers: k_edge_blocks_ovf left them at ovf_off[node] + j with the ring
+                // entry they multiply (tile-local); they move into the workgroup's pool with that entry rewritten like the others
+                // (record 0 of the pool is a zero block on slot `3 * tile_words` -- local node 0 of the reading tile --: what a
+                // lane with fewer records than its wave's longest row reads in the steps it has nothing for)
+                int32_t cnt = 0;
+                uint32_t off = 0;
+                if (tid == 0 && s == 0) {
+                    s_pool[0] = make_double2(0.0, 0.0);
+                    s_pool[1] = make_double2(0.0, __hiloint2double(0, 3 * tile_words));
+                }
+                if (nd < P.N) {
+                    constexpr int NBk = kPersistBlockEntries;
+                    const uint32_t info = P.row_info[nd];
+                    const int32_t n = (int32_t)(info & 63u), nblk = (info & 0x40u) ? n - 1 : n;
+                    if (info & 0x40u) flags.set(s, flags[s] | 32u); // a closed fan: its closing triangle is folded into the blocks
+                    const int32_t g0 = P.ovf_off[nd];
+                    cnt = nblk > NBk ? nblk - NBk : 0;
+                    off = 1u + (uint32_t)(g0 - P.ovf_off[(int64_t)t_first * B]);
+                    const double2 *src = (const double2 *)P.ovf_rec + 2 * (int64_t)g0;
+                    for (int32_t k = 0; k < cnt; ++k) {
+                        const double2 a = src[2 * k];
+                        double2 b = src[2 * k + 1];
+                        b.y = __hiloint2double(0, (int)(remap((uint32_t)__double2loint(b.y) & 0xfffu) & 0x7fffu));
+                        s_pool[2 * (off + (uint32_t)k)] = a;
+                        s_pool[2 * (off + (uint32_t)k) + 1] = b;
+                    }
+                    // an OPEN fan of more than NB entries: its last entry takes the place of register entry NB - 1 (the walk
+                    // telescopes the antisymmetric parts to u_last - u_first from the registers); k_edge_blocks_ovf has put the
+                    // last block there and the middle ones into the pool
+                    if (!(info & 0x40u) && n > NBk) {
+                        const uint32_t ww = P.ell16[ell_off[s] + (int64_t)((n - 1) >> 1) * B];
+                        const uint32_t last = remap(((n - 1) & 1) ? (ww >> 16) : (ww & 0xffffu)) & 0x7fffu;
+                        constexpr int kw = (NBk - 1) >> 1;
+                        w[s][kw] = ((NBk - 1) & 1) ? ((w[s][kw] & 0xffffu) | (last << 16)) : ((w[s][kw] & 0xffff0000u) | last);
+                    }
+                }
+                ovpk[s >> 1] |= ((off & 0xfffu) | ((uint32_t)cnt << 12)) << (16 * (s & 1));
+                int32_t m = 0;
+                for (int32_t c = 1; c <= 15; ++c)
+                    if (__any(cnt >= c ? 1 : 0)) m = c;
+                ovmax[s] = __builtin_amdgcn_readfirstlane(m);
+            }
         }
         if (EB) {
             // the fan closes inside the blocks when entry NB is entry 0's node again (k_edge_blocks folded that triangle in);
@@ -856,7 +918,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             constexpr int NBk = kPersistBlockEntries;
             static_assert(NBk + 1 <= 2 * kPersistRegs, "entry NB is looked at in the registers");
             const uint32_t e0 = w[s][0] & 0xffffu, eN = (NBk & 1) ? (w[s][NBk >> 1] >> 16) : (w[s][NBk >> 1] & 0xffffu);
-            if (tm.ent > NBk && !(eN & 0x8000u) && (eN & 0x7fffu) == (e0 & 0x7fffu)) flags.set(s, flags[s] | 32u);
+            if (!OV && tm.ent > NBk && !(eN & 0x8000u) && (eN & 0x7fffu) == (e0 & 0x7fffu)) flags.set(s, flags[s] | 32u);
             ring_pad_entries<kPersistRegs, NBk, 0x7fffu>(w[s], tm.ent);
         }
         if ((flags[s] & 20) == 20) put_granules(P.qg + 4 * nd, tag0, make_double2(0.0, 0.0)); // q_{-1} = 0, parity 0
@@ -888,7 +950,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
                     const int32_t g = P.halo_g[tm.hoff + rem];
                     const int32_t ot = g / B, ol = ot - t_first;
                     // a sibling tile owns it: this tile's walks read the owner's slots (rows all in the registers only)
-                    const bool sibling = tm.ent <= 2 * kPersistRegs && ol >= 0 && ol < P.tiles_per_wg && ot < t_end;
+                    const bool sibling = (OV || tm.ent <= 2 * kPersistRegs) && ol >= 0 && ol < P.tiles_per_wg && ot < t_end;
                     if (!sibling) {
                         cg[e] = g;
                         cl[e] = l * tile_words + rem;
@@ -932,8 +994,8 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
                 double2 *xy = smem + (size_t)l * tile_words;
                 if (!EB) xy[B + rem] = P.halo_xy[tm.hoff + rem];
                 const double2 hb = P.bP[hg[e]];
-                xy[2 * cap + rem] = make_double2(-hb.x, -hb.y); // halo r
-                xy[cap + B + rem] = make_double2(0.0, 0.0);     // halo p: its slot in the p image
+                xy[capx + cap + rem] = make_double2(-hb.x, -hb.y); // halo r
+                xy[capx + B + rem] = make_double2(0.0, 0.0);       // halo p: its slot in the p image
                 if (MG) { // a node another rank owns: its q comes through the window (slot s encoded as -2 - s)
                     const int32_t hs = P.halo_qslot[tm.hoff + rem];
                     if (hs >= 0) hg[e] = -2 - hs;
@@ -956,8 +1018,8 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
                     hloc[e] = l * tile_words + rem;
                     if (!EB) xy[B + rem] = P.halo_xy[tm.hoff + rem];
                     const double2 hb = P.bP[hg[e]];
-                    xy[2 * cap + rem] = make_double2(-hb.x, -hb.y);      // halo r
-                    xy[cap + B + rem] = make_double2(0.0, 0.0);        // halo p: its slot in the p image
+                    xy[capx + cap + rem] = make_double2(-hb.x, -hb.y);   // halo r
+                    xy[capx + B + rem] = make_double2(0.0, 0.0);         // halo p: its slot in the p image
                     if (MG) { // a node another rank owns: its q comes through the window (slot s encoded as -2 - s)
                         const int32_t hs = P.halo_qslot[tm.hoff + rem];
                         if (hs >= 0) hg[e] = -2 - hs;
@@ -1100,7 +1162,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             for (int s = 0; s < NPT; ++s) {
                 if (!(flags[s] & 8)) continue;
                 const int lt = t_lt(s);
-                double2 *xy = t_xy(s), *pim = xy + cap, *xs = pim + cap + maxh;
+                double2 *xy = t_xy(s), *pim = xy + capx, *xs = pim + cap + maxh;
                 const double2 po = pim[lt];
                 double2 xo = xs[lt];
                 xo.x += alpha * po.x;
@@ -1110,7 +1172,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         }
         auto update_slot = [&](int s) {
             const int lt = t_lt(s);
-            double2 *xy = t_xy(s), *pim = xy + cap;
+            double2 *xy = t_xy(s), *pim = xy + capx;
             const double2 po = pim[lt];
             const double2 qv = QL ? xy[lt] : q[s];
             double2 pn;
@@ -1135,13 +1197,13 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         for (int e = 0; e < NH; ++e)
             if (hg[e] != -1) {
                 double2 *hbase = smem + hloc[e]; // = tile base + position: coordinates at [B], p image at [cap + B], ...
-                double2 hrv = hbase[2 * cap], hpv = hbase[cap + B]; // the halo node's p lives in the p image itself
+                double2 hrv = hbase[capx + cap], hpv = hbase[capx + B]; // the halo node's p lives in the p image itself
                 hrv.x += alpha * hq[e].x;
                 hrv.y += alpha * hq[e].y;
                 hpv.x = -hrv.x + beta * hpv.x;
                 hpv.y = -hrv.y + beta * hpv.y;
-                hbase[2 * cap] = hrv;
-                hbase[cap + B] = hpv;
+                hbase[capx + cap] = hrv;
+                hbase[capx + B] = hpv;
             }
         MAG_STAMP(0) // scalars + vector updates issued
         __syncthreads();
@@ -1159,6 +1221,10 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
 #pragma unroll
                 for (int k = 0; k < (EB ? (kPersistBlockEntries + 1) / 2 : kPersistRegs); ++k) asm volatile("" : "+v"(w[s][k]));
         }
+        if (OV) { // ... and so do the pool positions: unpacked outside the loop they are eight registers, spilled
+#pragma unroll
+            for (int i = 0; i < (NPT + 1) / 2; ++i) asm volatile("" : "+v"(ovpk[i]));
+        }
 #pragma unroll
         for (int s = 0; s < NPT; ++s) {
 #if MAG_PERSIST_PRIO == 3
@@ -1172,14 +1238,19 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
 #endif
             if (!(flags[s] & 8)) continue;
             const int lt = t_lt(s);
-            const double2 *xy = t_xy(s), *pim = xy + cap;
+            const double2 *xy = t_xy(s), *pim = xy + capx;
             const double2 ca = xy[lt], pa = pim[lt];
             double fx = 0.0, fy = 0.0;
             {
                 const int32_t nent = __builtin_amdgcn_readfirstlane(ent[s]); // one tile per wave: a scalar
                 if (nent > 0) { // entries are biased slots relative to this tile (see the remap at the top)
                     const uint32_t toff = (uint32_t)(3 * tile_words);
-                    if (BLOCKS)
+                    if (OV) {
+                        const uint32_t oc = (ovpk[s >> 1] >> (16 * (s & 1))) & 0xffffu;
+                        ring_walk_blocks_ovf<kPersistRegs, NB, 0x7fffu>(w[s], pim - 3 * tile_words, pa, kappa, (flags[s] & 32u) != 0,
+                                                                        *reinterpret_cast<const double(*)[3 * NB]>(&wgt[s][0]), s_pool,
+                                                                        oc & 0xfffu, oc >> 12, ovmax[s], fx, fy);
+                    } else if (BLOCKS)
                         ring_walk_blocks<kPersistRegs, NB, 0x7fffu>(w[s], pim - 3 * tile_words, pa, kappa, (flags[s] & 32u) != 0,
                                                                     *reinterpret_cast<const double(*)[3 * NB]>(&wgt[s][0]), fx, fy);
                     else if (CACHED)
@@ -1225,7 +1296,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             const double ab = uniform_f64(alpha / beta);
             auto x_slot = [&](int s) {
                 const int lt = t_lt(s);
-                double2 *xy = t_xy(s), *pim = xy + cap, *xs = pim + cap + maxh;
+                double2 *xy = t_xy(s), *pim = xy + capx, *xs = pim + cap + maxh;
                 const double2 pj = pim[lt], rv = r[s];
                 double2 xo = xs[lt];
                 xo.x += ab * (pj.x + rv.x);
@@ -1270,7 +1341,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
     // x of iterate j-1 is in LDS; the verdict is the same in every workgroup
 #pragma unroll
     for (int s = 0; s < NPT; ++s)
-        if ((flags[s] & 24) == 24) P.x[node_of(s)] = (t_xy(s) + 2 * cap + maxh)[t_lt(s)];
+        if ((flags[s] & 24) == 24) P.x[node_of(s)] = (t_xy(s) + capx + cap + maxh)[t_lt(s)];
     if (blockIdx.x == 0 && tid == 0) {
         FusedState *st = P.st;
         st->bb = bb;
@@ -1460,46 +1531,55 @@ int persist_tiles_per_wg(int32_t B, int threads)
     return B == 256 || B == 512 ? persist_npt(threads) * threads / B : 0; // whole tiles: 768 x 3 / 512 = 4
 }
 
-size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh, int threads)
+// dynamic LDS of a launch; every instantiation also carries 256 bytes of static LDS (the library's __syncthreads_and / _or),
+// which the host's fit test adds (kPersistStaticLds)
+size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh, int threads, int eb_mode, int32_t pool)
 {
     const size_t tiles = (size_t)persist_tiles_per_wg(B, threads);
-    return tiles * (2 * (size_t)cap + (size_t)maxh + (size_t)B) * 16 + 2 * 256 * 16 +
-           (4 * ((size_t)threads / 64) + 4 + 4 * 32) * 8 + 16;
+    const size_t capx = eb_mode == 2 ? (size_t)B : (size_t)cap; // with overflow blocks the first area holds q of the owned nodes only
+    return tiles * (capx + (size_t)cap + (size_t)maxh + (size_t)B) * 16 + 2 * 256 * 16 +
+           (4 * ((size_t)threads / 64) + 4 + 4 * 32) * 8 + 16 + (eb_mode == 2 ? 32 * (size_t)pool : 0);
 }
 
 template <int THREADS>
-static void persist_launch_t(const PersistParams &P, int32_t B, int32_t grid, size_t lds, bool edge_blocks, hipStream_t s)
+static void persist_launch_t(const PersistParams &P, int32_t B, int32_t grid, size_t lds, int eb_mode, hipStream_t s)
 {
     if (P.nranks > 1) {
-        if (edge_blocks) {
+        if (eb_mode == 1) {
             if (B == 256)
-                k_cg_persist<256, true, THREADS, true><<<grid, THREADS, lds, s>>>(P);
+                k_cg_persist<256, true, THREADS, 1><<<grid, THREADS, lds, s>>>(P);
             else
-                k_cg_persist<512, true, THREADS, true><<<grid, THREADS, lds, s>>>(P);
+                k_cg_persist<512, true, THREADS, 1><<<grid, THREADS, lds, s>>>(P);
         } else if (B == 256)
-            k_cg_persist<256, true, THREADS, false><<<grid, THREADS, lds, s>>>(P);
+            k_cg_persist<256, true, THREADS, 0><<<grid, THREADS, lds, s>>>(P);
         else
-            k_cg_persist<512, true, THREADS, false><<<grid, THREADS, lds, s>>>(P);
-    } else if (edge_blocks) {
+            k_cg_persist<512, true, THREADS, 0><<<grid, THREADS, lds, s>>>(P);
+    } else if (eb_mode == 2) {
         if (B == 256)
-            k_cg_persist<256, false, THREADS, true><<<grid, THREADS, lds, s>>>(P);
+            k_cg_persist<256, false, THREADS, 2><<<grid, THREADS, lds, s>>>(P);
         else
-            k_cg_persist<512, false, THREADS, true><<<grid, THREADS, lds, s>>>(P);
+            k_cg_persist<512, false, THREADS, 2><<<grid, THREADS, lds, s>>>(P);
+    } else if (eb_mode == 1) {
+        if (B == 256)
+            k_cg_persist<256, false, THREADS, 1><<<grid, THREADS, lds, s>>>(P);
+        else
+            k_cg_persist<512, false, THREADS, 1><<<grid, THREADS, lds, s>>>(P);
     } else if (B == 256)
-        k_cg_persist<256, false, THREADS, false><<<grid, THREADS, lds, s>>>(P);
+        k_cg_persist<256, false, THREADS, 0><<<grid, THREADS, lds, s>>>(P);
     else
-        k_cg_persist<512, false, THREADS, false><<<grid, THREADS, lds, s>>>(P);
+        k_cg_persist<512, false, THREADS, 0><<<grid, THREADS, lds, s>>>(P);
 }
 
-// edge_blocks: every row of the mesh qualifies for the edge-block instantiation (ring16's flag)
-void persist_launch(const PersistParams &P, int32_t B, int32_t grid, int threads, bool edge_blocks, hipStream_t s)
+// eb_mode: 1 every row of the mesh qualifies for the edge-block instantiation (ring16's flag), 2 with overflow records in LDS
+// (single GPU; the host has checked the pool against the LDS), 0 the triangle walk
+void persist_launch(const PersistParams &P, int32_t B, int32_t grid, int threads, int eb_mode, hipStream_t s)
 {
-    const size_t lds = persist_lds_bytes(B, P.cap, P.maxh, threads);
-    edge_blocks = edge_blocks && kPersistEdgeBlocks;
+    if (!kPersistEdgeBlocks || (eb_mode == 2 && P.nranks > 1)) eb_mode = 0;
+    const size_t lds = persist_lds_bytes(B, P.cap, P.maxh, threads, eb_mode, P.pool_cap);
 #ifdef MAG_PERSIST_768
-    if (threads == 768) return persist_launch_t<768>(P, B, grid, lds, false, s);
+    if (threads == 768) return persist_launch_t<768>(P, B, grid, lds, 0, s);
 #endif
-    persist_launch_t<512>(P, B, grid, lds, edge_blocks, s);
+    persist_launch_t<512>(P, B, grid, lds, eb_mode, s);
 }
 
 int persist_block_entries() { return kPersistBlockEntries; }
@@ -1537,11 +1617,114 @@ __global__ void __launch_bounds__(256) k_edge_blocks(const PersistParams P, doub
     for (int c = 0; c < 3 * NB; ++c) kbg[(int64_t)c * P.kb_stride + nd] = kb[c];
 }
 
-void edge_blocks_build(const PersistParams &P, int32_t B, double *kblocks, hipStream_t s)
+// The same for meshes whose rows are single fans of ANY length (EBM == 2).  The row is streamed from the ring table, one
+// triangle at a time: triangle k (between entries k - 1 and k) contributes its K_ab to block k - 1 and its K_ac to block k --
+// or to block 0 when it closes the fan (the row's last entry repeats its first: row_info bit 6), so a closed fan of valence
+// v is v blocks.  Block j >= 1 is complete once triangle j + 1 is through; block 0 is held to the end.  Blocks below NB go to
+// the value-major arrays the registers are loaded from, block j >= NB to the node's overflow records, at ovf_off[node] +
+// j - NB, with the ring entry (tile-local id) it multiplies.  Per block the same two-term sums in the same order as
+// ring_blocks: a structured mesh gets the same bits from either kernel.
+template <int B>
+__global__ void __launch_bounds__(256) k_edge_blocks_ovf(const PersistParams P, double *kbg)
+{
+    constexpr int NB = kPersistBlockEntries;
+    const int64_t nd = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int32_t t = (int32_t)(nd / B), lt = (int32_t)(nd % B);
+    if (t >= P.T) return;
+    const TileMeta tm = P.meta[t];
+    const uint32_t info = nd < P.N ? P.row_info[nd] : 0u;
+    const int32_t n = (info & 0x80u) ? (int32_t)(info & 63u) : 0;
+    const bool closed = (info & 0x40u) != 0;
+    const int32_t nblk = closed ? n - 1 : n;
+    auto emit = [&](int32_t j, double v0, double v1, double v2, uint32_t id) {
+        if (j < NB) {
+            kbg[(int64_t)(3 * j + 0) * P.kb_stride + nd] = v0;
+            kbg[(int64_t)(3 * j + 1) * P.kb_stride + nd] = v1;
+            kbg[(int64_t)(3 * j + 2) * P.kb_stride + nd] = v2;
+        } else {
+            double2 *rec = (double2 *)P.ovf_rec + 2 * ((int64_t)P.ovf_off[nd] + (j - NB));
+            rec[0] = make_double2(v0, v1);
+            rec[1] = make_double2(v2, __hiloint2double(0, (int)id));
+        }
+    };
+    for (int32_t j = nblk > 0 ? nblk : 0; j < NB; ++j) emit(j, 0.0, 0.0, 0.0, 0u); // blocks the row does not have
+    // An open fan of more than NB entries keeps its LAST block in register position NB - 1 and its middle blocks NB - 1 ..
+    // n - 2 in the pool: u_first and u_last, which the walk's telescoped antisymmetric part needs, are then always register
+    // entries (the on-chip kernel moves the row's last ring entry into position NB - 1 to match).
+    const bool open_long = !closed && n > NB;
+    auto place = [&](int32_t j, double v0, double v1, double v2, uint32_t id) {
+        if (open_long && j >= NB - 1) j = j == n - 1 ? NB - 1 : j + 1;
+        emit(j, v0, v1, v2, id);
+    };
+    if (n < 2) {
+        if (nblk == 1) emit(0, 0.0, 0.0, 0.0, 0u); // one entry, no triangle
+        return;
+    }
+    auto entry = [&](int32_t k) {
+        const uint32_t ww = P.ell16[tm.ell_off + lt + (int64_t)(k >> 1) * B];
+        return (k & 1) ? (ww >> 16) : (ww & 0xffffu);
+    };
+    auto xy_of = [&](uint32_t lid) -> double2 {
+        if (lid < (uint32_t)B) {
+            const int64_t g = (int64_t)t * B + lid;
+            return g < P.N ? P.xyP[g] : make_double2(0.0, 0.0);
+        }
+        return P.halo_xy[tm.hoff + (int32_t)(lid - B)];
+    };
+    const double2 ca = P.xyP[nd];
+    const double2 z = make_double2(0.0, 0.0), ex = make_double2(1.0, 0.0), ey = make_double2(0.0, 1.0);
+    const uint32_t id0 = entry(0) & 0xfffu;
+    double2 pd;
+    {
+        const double2 cxy = xy_of(id0);
+        pd = make_double2(cxy.x - ca.x, cxy.y - ca.y);
+    }
+    double k0[3] = {0.0, 0.0, 0.0};    // block 0, held to the end
+    double carry[3] = {0.0, 0.0, 0.0}; // K_ac of the triangle before entry k - 1: the first term of block k - 1
+    uint32_t idprev = id0;
+    for (int32_t k = 1; k < n; ++k) {
+        const uint32_t id = entry(k) & 0xfffu;
+        const double2 cxy = xy_of(id);
+        const double2 d = make_double2(cxy.x - ca.x, cxy.y - ca.y);
+        const double twoA = pd.x * d.y - d.x * pd.y;
+        const double wt = P.c0 * fast_rcp(twoA);
+        double b00 = 0.0, b10 = 0.0, b01 = 0.0, b11 = 0.0, c00 = 0.0, c10 = 0.0, c01 = 0.0, c11 = 0.0;
+        fan_force_w<double2, double>(pd, ex, d, z, wt, P.nu, P.h, b00, b10); // K_ab, first column
+        fan_force_w<double2, double>(pd, ey, d, z, wt, P.nu, P.h, b01, b11);
+        fan_force_w<double2, double>(pd, z, d, ex, wt, P.nu, P.h, c00, c10); // K_ac
+        fan_force_w<double2, double>(pd, z, d, ey, wt, P.nu, P.h, c01, c11);
+        const double bs = 0.5 * (b01 + b10), cs = 0.5 * (c01 + c10);
+        if (k == 1) { // block 0 = K_ab of triangle 1 (+ K_ac of the closing triangle, below)
+            k0[0] = 0.0 + b00;
+            k0[1] = 0.0 + bs;
+            k0[2] = 0.0 + b11;
+        } else {
+            place(k - 1, carry[0] + b00, carry[1] + bs, carry[2] + b11, idprev);
+        }
+        carry[0] = 0.0 + c00;
+        carry[1] = 0.0 + cs;
+        carry[2] = 0.0 + c11;
+        pd = d;
+        idprev = id;
+    }
+    if (closed) { // the last triangle closes onto entry 0
+        place(0, k0[0] + carry[0], k0[1] + carry[1], k0[2] + carry[2], id0);
+    } else {
+        place(0, k0[0], k0[1], k0[2], id0);
+        place(n - 1, carry[0], carry[1], carry[2], idprev);
+    }
+}
+
+void edge_blocks_build(const PersistParams &P, int32_t B, double *kblocks, int eb_mode, hipStream_t s)
 {
     const int64_t npad = (int64_t)P.T * B;
     const unsigned blocks = (unsigned)((npad + 255) / 256);
-    if (B == 256)
+    if (eb_mode == 2) {
+        if (B == 256)
+            k_edge_blocks_ovf<256><<<blocks, 256, 0, s>>>(P, kblocks);
+        else
+            k_edge_blocks_ovf<512><<<blocks, 256, 0, s>>>(P, kblocks);
+    } else if (B == 256)
         k_edge_blocks<256><<<blocks, 256, 0, s>>>(P, kblocks);
     else
         k_edge_blocks<512><<<blocks, 256, 0, s>>>(P, kblocks);
@@ -1575,9 +1758,10 @@ __global__ void __launch_bounds__(256) k_mark_external(const int32_t *halo_g, co
 }
 
 void mark_external(const int32_t *halo_g, const TileMeta *meta, int32_t t0, int32_t t1, int32_t B, int32_t k, uint8_t *maskP,
-                   hipStream_t s)
+                   bool all_rows, hipStream_t s)
 {
-    if (t1 > t0) k_mark_external<<<t1 - t0, 256, 0, s>>>(halo_g, meta, B, k, 2 * kPersistRegs, t0, t1, maskP);
+    if (t1 > t0)
+        k_mark_external<<<t1 - t0, 256, 0, s>>>(halo_g, meta, B, k, all_rows ? 0x7fffffff : 2 * kPersistRegs, t0, t1, maskP);
 }
 
 // bit 2 of the node mask: some tile reads this node through its halo list, so its owner must publish q

@@ -461,7 +461,7 @@ void fill_ell16(const int32_t *inc_off, const uint32_t *inc, const int32_t *conn
 constexpr int kRingMaxDeg = 32;
 
 __global__ void __launch_bounds__(256) k_ring16(const int32_t *tile_deg, const int64_t *tile_off, int32_t B, uint32_t *ell,
-                                                int32_t *tile_rdeg, int32_t nb)
+                                                int32_t *tile_rdeg, int32_t nb, uint8_t *row_info)
 {
     const int32_t t = blockIdx.x;
     const int32_t td = tile_deg[t];
@@ -471,7 +471,12 @@ __global__ void __launch_bounds__(256) k_ring16(const int32_t *tile_deg, const i
     // kernel can fold the mesh into nb edge blocks per node (persist.hip, EB instantiation); one row that is not -- several
     // fans at a node, a closed fan of valence > nb, an open one of > nb - 1 triangles -- and the whole mesh keeps the
     // triangle walk.  tile_rdeg[2 T] collects the answer (0: every row qualifies).
-    bool plain = true;
+    // Round 4: bit 0 of that word as before ("some row is not a plain fan of <= nb entries"), bit 1 = some row is not ONE fan
+    // at all (several fans at a node, more than kRingMaxDeg triangles).  A mesh with bit 1 clear can still run the edge-block
+    // kernel: rows with more than nb blocks keep the blocks beyond nb in LDS (persist.hip, EBM == 2), which is what gmsh-type
+    // meshes need -- a quarter of their nodes have seven neighbours.  row_info[node] says what that needs per row: bits 0-5 the
+    // row's entries n, bit 6 = the fan is closed (entry n - 1 repeats entry 0), bit 7 = the row is one fan.
+    bool plain = true, single = true;
     for (int l = threadIdx.x; l < B; l += 256) {
         uint32_t *row = dst + l; // row[k * B], k < td
         int d = 0;
@@ -484,6 +489,8 @@ __global__ void __launch_bounds__(256) k_ring16(const int32_t *tile_deg, const i
             words = d;
             emax = 2 * d > emax ? 2 * d : emax;
             plain = false;
+            single = false;
+            if (row_info) row_info[(int64_t)t * B + l] = 0;
         } else if (d > 0) {
             uint32_t pr[kRingMaxDeg];
             uint16_t out[2 * kRingMaxDeg];
@@ -527,8 +534,15 @@ __global__ void __launch_bounds__(256) k_ring16(const int32_t *tile_deg, const i
             }
             words = (n + 1) / 2;
             emax = n > emax ? n : emax;
-            for (int k = 1; k < n; ++k) plain &= !(out[k] & 0x8000u); // a second fan
+            bool one = true;
+            for (int k = 1; k < n; ++k) one &= !(out[k] & 0x8000u); // a second fan
+            plain &= one;
             plain &= n <= nb || (n == nb + 1 && (out[nb] & 0xfffu) == (out[0] & 0xfffu));
+            one &= n < 64;
+            single &= one;
+            if (row_info)
+                row_info[(int64_t)t * B + l] = (uint8_t)((one ? 0x80u | (uint32_t)n : 0u) |
+                                                         (one && n >= 3 && (out[n - 1] & 0xfffu) == (out[0] & 0xfffu) ? 0x40u : 0u));
             // Padding repeats the last neighbour with the break bit: a walker may treat EVERY entry of the tile's
             // row length as present (no per-entry test), the repeated entry closes no triangle.
             const uint32_t pad = (uint32_t)(out[n - 1] & 0xfffu) | 0x8000u;
@@ -538,20 +552,67 @@ __global__ void __launch_bounds__(256) k_ring16(const int32_t *tile_deg, const i
             }
         } else {
             for (int k = 0; k < td; ++k) row[(int64_t)k * B] = 0x80008000u; // no triangles: slot 0, break, throughout
+            if (row_info) row_info[(int64_t)t * B + l] = 0x80u; // no entries, no blocks
         }
         wmax = words > wmax ? words : wmax;
     }
     if (wmax > 0) atomicMax(&tile_rdeg[t], wmax);
     if (emax > 0) atomicMax(&tile_rdeg[gridDim.x + t], emax); // second half of the array: entries of the longest row
-    if (!plain) atomicOr(&tile_rdeg[2 * gridDim.x], 1);
+    if (!plain || !single) atomicOr(&tile_rdeg[2 * gridDim.x], (plain ? 0 : 1) | (single ? 0 : 2));
 }
 
 void ring16(const int32_t *tile_deg, const int64_t *tile_off, int32_t B, int32_t T, uint32_t *ell, int32_t *tile_rdeg,
-            int32_t block_entries, hipStream_t s)
+            int32_t block_entries, uint8_t *row_info, hipStream_t s)
 {
-    // [0, T): words, [T, 2T): entries of the longest row, [2T]: some row does not qualify for edge blocks
+    // [0, T): words, [T, 2T): entries of the longest row, [2T]: bit 0 some row is not a plain short fan, bit 1 some row is
+    // not one fan (see k_ring16)
     (void)hipMemsetAsync(tile_rdeg, 0, 4 * (2 * (size_t)T + 1), s);
-    k_ring16<<<T, 256, 0, s>>>(tile_deg, tile_off, B, ell, tile_rdeg, block_entries);
+    k_ring16<<<T, 256, 0, s>>>(tile_deg, tile_off, B, ell, tile_rdeg, block_entries, row_info);
+}
+
+// Edge blocks beyond the nb a node keeps in registers (persist.hip, EBM == 2): per node of the padded Hilbert order the
+// number of blocks its row needs above nb -- n - 1 for a closed fan of n entries (the closing triangle is folded into
+// blocks n - 2 and 0), n for an open one.  The exclusive scan of these counts addresses the overflow records.
+__global__ void __launch_bounds__(256) k_ovf_counts(const uint8_t *row_info, int64_t npad, int32_t nb, int32_t *cnt)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i > npad) return;
+    int32_t c = 0;
+    if (i < npad) {
+        const uint32_t info = row_info[i];
+        const int32_t n = (int32_t)(info & 63u), nblk = (info & 0x40u) ? n - 1 : n;
+        c = nblk > nb ? nblk - nb : 0;
+    }
+    cnt[i] = c; // (cnt[npad] = 0: the scan's last entry is the total)
+}
+
+void ovf_counts(const uint8_t *row_info, int64_t npad, int32_t nb, int32_t *cnt, hipStream_t s)
+{
+    k_ovf_counts<<<blocks_for(npad + 1, 256), 256, 0, s>>>(row_info, npad, nb, cnt);
+}
+
+// Largest number of overflow records any workgroup of the on-chip kernel (k tiles each, tiles [t0, t1)) has to hold, and
+// the largest count of a single node: out[0], out[1] (zeroed by the caller).
+__global__ void __launch_bounds__(256) k_ovf_limits(const int32_t *off, int32_t B, int32_t k, int32_t t0, int32_t t1,
+                                                    int32_t *out)
+{
+    const int32_t g = blockIdx.x; // workgroup of the on-chip kernel
+    const int64_t n0 = (int64_t)(t0 + g * k) * B;
+    int64_t n1 = n0 + (int64_t)k * B;
+    if (n1 > (int64_t)t1 * B) n1 = (int64_t)t1 * B;
+    int32_t m = 0;
+    for (int64_t i = n0 + threadIdx.x; i < n1; i += 256) {
+        const int32_t c = off[i + 1] - off[i];
+        m = c > m ? c : m;
+    }
+    if (m > 0) atomicMax(&out[1], m);
+    if (threadIdx.x == 0) atomicMax(&out[0], off[n1] - off[n0]);
+}
+
+void ovf_limits(const int32_t *off, int32_t B, int32_t k, int32_t t0, int32_t t1, int32_t *out, hipStream_t s)
+{
+    const int32_t grid = (t1 - t0 + k - 1) / k;
+    if (grid > 0) k_ovf_limits<<<grid, 256, 0, s>>>(off, B, k, t0, t1, out);
 }
 
 // --------------------------------------------------------- CSR pattern ---

@@ -201,6 +201,36 @@ def perturb(mesh, amount, seed=12345):
     return Mesh(mesh.xy + d, mesh.conn.copy(), mesh.name + "_pert")
 
 
+def frontal_like(n, jitter=0.4, seed=1, lx=1.0, name=None):
+    """Unstructured stand-in for what `gmsh geom.geo -2` hands solver::run (mesher.rs:501-506; gmsh is not installed):
+    an equilateral lattice of pitch lx / n on the unit square (straight boundary frame), interior points moved by uniform
+    +-jitter pitches, Delaunay-triangulated (scipy), CCW.  At jitter 0.4 the valence histogram is that of a frontal
+    mesh: half the nodes have six neighbours, a quarter five, a quarter seven or more (3 % eight, a few nine or ten).
+    2 n^2 * 1.155 triangles; deterministic for a given (n, jitter, seed)."""
+    from scipy.spatial import Delaunay
+    h = lx / n
+    rows = int(round(lx / (h * np.sqrt(3.0) / 2.0)))
+    hy = lx / rows
+    rng = np.random.default_rng(seed)
+    pts = []
+    for j in range(rows + 1):
+        xs = np.arange(n + 1) * h if j % 2 == 0 else np.concatenate([[0.0], (np.arange(n) + 0.5) * h, [lx]])
+        p = np.stack([xs, np.full_like(xs, j * hy)], axis=1)
+        d = rng.uniform(-jitter * h, jitter * h, size=p.shape)
+        inner = (p[:, 0] > 1e-12) & (p[:, 0] < lx - 1e-12) & (j > 0) & (j < rows)
+        p[inner] += d[inner]
+        pts.append(p)
+    xy = np.concatenate(pts)
+    tri = Delaunay(xy).simplices.astype(np.int64)
+    a = xy[tri]
+    area = 0.5 * ((a[:, 1, 0] - a[:, 0, 0]) * (a[:, 2, 1] - a[:, 0, 1]) - (a[:, 2, 0] - a[:, 0, 0]) * (a[:, 1, 1] - a[:, 0, 1]))
+    tri = tri[np.abs(area) > 1e-9 * h * h]  # (collinear frame points can leave a sliver of zero area)
+    area = area[np.abs(area) > 1e-9 * h * h]
+    flip = area < 0
+    tri[flip] = tri[flip][:, ::-1]
+    return Mesh(np.ascontiguousarray(xy), np.ascontiguousarray(tri.astype(np.int32)), name or f"frontal_{n}_j{jitter}_s{seed}")
+
+
 def clockwise(mesh):
     """Reverse every element (what mesher.rs:522-526 check_ccw does to all elements
     of a fine mesh: signed area < 1.0 => reversed => K negative semidefinite)."""

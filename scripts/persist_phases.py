@@ -7,7 +7,7 @@ same solves with the product build (no stamp executes) for the un-instrumented t
 runs the 768 x 3 workgroup shape -- only in libraries built with -DMAG_PERSIST_768 (round 3's record,
 profiles/r03_persist_phases.json, has both: 768 was slower and is not instantiated in the product).
 
-    python scripts/persist_phases.py [out.json]        (on the GPU box; default profiles/r03_persist_phases.json)
+    python scripts/persist_phases.py [--triangles] [out.json]   (on the GPU box; default profiles/r03_persist_phases.json)
 """
 import json
 import os
@@ -28,12 +28,17 @@ with Context(device=0, stop_mode=_lib.MAG_STOP_REL, tol=1e-8, cg_variant=2) as c
     c.upload_problem(prob)
     c.run(); c.run()
     st = c.stats()
-print(json.dumps({k: st[k] for k in ("iterations", "ms_cg", "cg_kernel", "num_tiles", "persist_timeout")}))
+print(json.dumps({k: st[k] for k in ("iterations", "ms_cg", "cg_kernel", "num_tiles", "persist_timeout", "edge_blocks")}))
 """ % ROOT
+
+
+TRIANGLES = "--triangles" in sys.argv  # the triangle-walk instantiation (what a mesh that does not qualify for edge blocks runs)
 
 
 def run(workload, threads, stamps_file):
     env = dict(os.environ, MAG_TUNE_PERSIST_THREADS=str(threads))
+    if TRIANGLES:
+        env["MAG_TUNE_PERSIST_TRIANGLES"] = "1"
     if stamps_file:
         env["MAG_LIB_PATH"] = os.environ.get("MAG_STAMPS_LIB") or os.path.join(ROOT, "magnetite_amd", "libmagnetite_hip_stamps.so")
         env["MAG_TUNE_PERSIST_STAMPS"] = stamps_file
@@ -44,12 +49,15 @@ def run(workload, threads, stamps_file):
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--shapes")]
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
     shapes = [int(x) for a in sys.argv[1:] if a.startswith("--shapes") for x in a.split("=")[1].split(",")] or [512]
     out_path = args[0] if args else os.path.join(ROOT, "profiles", "r03_persist_phases.json")
     out = {"what": __doc__.strip().splitlines()[0], "clock": "s_memrealtime, 100 MHz (10 ns ticks)",
-           "iterations_stamped": "200..1199 of each solve, lane 0 of every workgroup", "runs": []}
-    for workload in ("hole1m", "plate100k"):
+           "iterations_stamped": "200..1199 of each solve, lane 0 of every workgroup",
+           "instantiation": "triangle walk (MAG_TUNE_PERSIST_TRIANGLES=1)" if TRIANGLES else "default (edge blocks where the mesh qualifies)",
+           "runs": []}
+    workloads = [x for a in sys.argv[1:] if a.startswith("--workloads=") for x in a.split("=")[1].split(",")] or ["hole1m", "plate100k"]
+    for workload in workloads:
         for threads in shapes:
             plain = run(workload, threads, None)
             f = f"/tmp/persist_stamps_{workload}_{threads}.csv"
@@ -63,7 +71,7 @@ def main():
             hi = [max(w[k] for w in per_wg) for k in range(7)]
             sweeps = sum(r[7] / r[-1] for r in rows) / n
             d = {"workload": workload, "threads": threads, "nodes_per_lane": 3 if threads == 768 else 4, "workgroups": n,
-                 "iterations": plain["iterations"], "cg_kernel": plain["cg_kernel"],
+                 "iterations": plain["iterations"], "cg_kernel": plain["cg_kernel"], "edge_blocks": st["edge_blocks"],
                  "us_per_iteration_product_build": plain["ms_cg"] * 1e3 / plain["iterations"],
                  "us_per_iteration_stamped_build": st["ms_cg"] * 1e3 / st["iterations"],
                  "phases_us_mean_over_workgroups": dict(zip(PHASES, mean)),

@@ -1061,19 +1061,102 @@ def test_on_chip_edge_blocks_match_the_oracle_and_the_triangle_walk(built, case,
     assert np.array_equal(out["u"], again["u"])              # bitwise reproducible
 
 
-def test_on_chip_edge_blocks_are_refused_where_a_row_does_not_fit(built, monkeypatch):
-    """One node of valence 12 in an otherwise structured mesh (k_ring16's flag), and a mesh of valence-8 nodes: the whole
-    mesh keeps the triangle walk."""
+def _poisson_delaunay(n_pts, seed):
+    """Random points in the unit square plus a boundary frame, Delaunay-triangulated: valences from 3 to 12 and more."""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(seed)
+    m = int(np.sqrt(n_pts))
+    t = np.linspace(0.0, 1.0, m + 1)
+    frame = np.concatenate([np.stack([t, 0 * t], 1), np.stack([t, 0 * t + 1], 1), np.stack([0 * t[1:-1], t[1:-1]], 1),
+                            np.stack([0 * t[1:-1] + 1, t[1:-1]], 1)])
+    pts = np.concatenate([frame, rng.uniform(0.5 / m, 1 - 0.5 / m, size=(n_pts, 2))])
+    tri = Delaunay(pts).simplices.astype(np.int64)
+    a = pts[tri]
+    area = 0.5 * ((a[:, 1, 0] - a[:, 0, 0]) * (a[:, 2, 1] - a[:, 0, 1]) - (a[:, 2, 0] - a[:, 0, 0]) * (a[:, 1, 1] - a[:, 0, 1]))
+    keep = np.abs(area) > 1e-12
+    tri, area = tri[keep], area[keep]
+    tri[area < 0] = tri[area < 0][:, ::-1]
+    return meshgen.Mesh(pts, np.ascontiguousarray(tri.astype(np.int32)), f"poisson_{n_pts}_{seed}")
+
+
+@pytest.mark.parametrize("case", ["frontal", "frontal_shuffled_cw", "frontal_two_tiles_per_wg", "disc8", "disc9", "disc12", "poisson",
+                                  "structured_forced"])
+def test_on_chip_edge_blocks_with_overflow_match_the_oracle_and_the_triangle_walk(built, case, monkeypatch):
+    """Round 4: meshes whose rows are single fans of ANY length -- what gmsh's frontal mesher hands solver::run
+    (mesher.rs:501-506): a quarter of the nodes with seven or more neighbours -- run the edge-block kernel with the blocks
+    beyond the six in registers as records in an LDS pool (mag_stats.edge_blocks == 2; k_edge_blocks_ovf,
+    ring_walk_blocks_ovf).  Jittered-lattice Delaunay meshes (valence 4-10), a hub of valence 12, disc centres of valence 8
+    and 9 (closed fans folded onto block 0), random-point Delaunay (valence up to 12+), shuffled numbering, clockwise
+    elements, two tiles per workgroup (sibling slots in the pool's entries), and a structured mesh forced through the
+    overflow instantiation (no overflow records at all: the compact LDS layout alone).  Against the oracle and against the
+    triangle walk of the same library."""
     monkeypatch.setenv("MAG_TUNE_PERSIST_MIN_K", "1")
-    for mesh in (_plate_with_a_hub(60), meshgen.perturb(_disc(8, 12), 0.05, 2)):
-        p = meshgen.config_fixed_left_pull_right(mesh) if "hub" in mesh.name else meshgen.apply_boundary_rules(
-            mesh, [meshgen.BoundaryRule("hold", x_max=-7.0, ux=0.0, uy=0.0), meshgen.BoundaryRule("pull", x_min=7.0, ux=0.01, fy=0.0)])
+    kw = {}
+    if case == "frontal":
+        p = meshgen.config_fixed_left_pull_right(meshgen.frontal_like(100, 0.4, 3))
+    elif case == "frontal_shuffled_cw":
+        p = meshgen.config_fixed_left_point_load(meshgen.clockwise(meshgen.shuffle(meshgen.frontal_like(90, 0.45, 5), 8)))
+    elif case == "frontal_two_tiles_per_wg":
+        p = meshgen.config_fixed_left_pull_right(meshgen.shuffle(meshgen.frontal_like(345, 0.4, 7), 2))
+        assert p.mesh.num_nodes > 256 * 512
+        kw = dict(stop_mode=MAG_STOP_REL, tol=1e-9)
+    elif case.startswith("disc"):
+        m = int(case[4:])
+        mesh = meshgen.perturb(_disc(m, 12), 0.05, 2)
+        p = meshgen.apply_boundary_rules(mesh, [meshgen.BoundaryRule("hold", x_max=-7.0, ux=0.0, uy=0.0),
+                                                meshgen.BoundaryRule("pull", x_min=7.0, ux=0.01, fy=0.0)])
+    elif case == "poisson":
+        p = meshgen.config_fixed_left_pull_right(_poisson_delaunay(9000, 4))
+    else:
+        monkeypatch.setenv("MAG_TUNE_PERSIST_FORCE_OVERFLOW", "1")
+        p = meshgen.config_fixed_left_pull_right(meshgen.plate_with_holes(96))
+    ref = oracle_run(p, **({"stop_mode": oracle.STOP_REL, "tol": 1e-9} if kw else {}))
+    with Context(device=0, tile_nodes=512, **kw) as c:
+        out = c.solve(p)
+        st = c.stats()
+        monkeypatch.setenv("MAG_TUNE_PERSIST_TRIANGLES", "1")
+        walk = c.solve(p)
+        st_walk = c.stats()
+        monkeypatch.delenv("MAG_TUNE_PERSIST_TRIANGLES")
+        again = c.solve(p)
+    assert st["cg_kernel"] == 2 and st["edge_blocks"] == 2, (case, st["edge_blocks"])
+    assert st_walk["cg_kernel"] == 2 and st_walk["edge_blocks"] == 0, case
+    assert out["converged"] == 1 and abs(out["iterations"] - ref["iterations"]) <= max(3, ref["iterations"] // 50), case
+    for key in ("u", "f", "stress"):  # (a relative stop at 1e-9 leaves the reactions and stresses at ~1e-8)
+        assert rel(out[key], ref[key]) <= (TOL_U if key == "u" or not kw else 1e-7), (case, key)
+    # (the reference's stop rule runs to round-off, where the iteration count wobbles with the order of the sums)
+    assert rel(out["u"], walk["u"]) <= 1e-9 and abs(out["iterations"] - walk["iterations"]) <= max(3, ref["iterations"] // 50), case
+    assert np.array_equal(out["u"], again["u"])              # bitwise reproducible
+    if case == "structured_forced":  # the same blocks as the register-only instantiation: the same solution to rounding
+        monkeypatch.delenv("MAG_TUNE_PERSIST_FORCE_OVERFLOW")
+        with Context(device=0, tile_nodes=512) as c:
+            plain = c.solve(p)
+            assert c.stats()["edge_blocks"] == 1
+        assert rel(out["u"], plain["u"]) <= 1e-12 and out["iterations"] == plain["iterations"]
+
+
+def test_on_chip_edge_blocks_are_refused_where_a_row_does_not_fit(built, monkeypatch):
+    """A node whose triangles form TWO fans (a plate with one cell pair removed so that two corner cells touch only at a
+    node; the hanging midpoints around the valence-12 hub of _plate_with_a_hub) keeps the whole mesh on the triangle walk
+    (k_ring16's flag, bit 1); so does a single-fan mesh with the overflow instantiation switched off
+    (MAG_TUNE_PERSIST_NO_OVERFLOW=1: round 3's all-or-nothing rule)."""
+    monkeypatch.setenv("MAG_TUNE_PERSIST_MIN_K", "1")
+    xy, tri, cx, cy = meshgen._grid(64, 64, 1.0, 1.0)  # cells (20, 20) and (21, 21) removed: node (21, 21) keeps two cells
+    keep = np.ones(cx.shape[0], dtype=bool)             # that touch only at the node -- two fans
+    keep[[20 * 64 + 20, 21 * 64 + 21]] = False
+    two_fans = meshgen._compact(xy, tri, keep, "pinched_plate")
+    for mesh, env in ((two_fans, None), (_plate_with_a_hub(60), None), (meshgen.frontal_like(80, 0.4, 2), "MAG_TUNE_PERSIST_NO_OVERFLOW")):
+        if env:
+            monkeypatch.setenv(env, "1")
+        p = meshgen.config_fixed_left_pull_right(mesh)
         ref = oracle_run(p)
         with Context(device=0, tile_nodes=512) as c:
             out = c.solve(p)
             st = c.stats()
         assert st["cg_kernel"] == 2 and st["edge_blocks"] == 0, mesh.name
         assert rel(out["u"], ref["u"]) <= TOL_U, mesh.name
+        if env:
+            monkeypatch.delenv(env)
 
 
 def _plate_with_removed_cells(nx, seed, rects, p_random):
