@@ -290,6 +290,39 @@ def hbm_resident_leg(device, reps):
             "seconds": time.perf_counter() - t0}
 
 
+def unstructured_leg(device, tol, reps=3):
+    """The drop-in case next to the headline: solver::run is handed gmsh meshes (mesher.rs:501-506), not structured plates.
+    frontal1m = 1 006 602 triangles of a jittered equilateral lattice, Delaunay (meshgen.frontal_like: a quarter of the
+    nodes with seven or more neighbours, like a frontal mesh): `reps` whole mag_run steps after one warm-up, the same stop
+    rule as the headline, the solution verified by its true residual."""
+    import numpy as np
+
+    from magnetite_amd import Context, _lib
+    t0 = time.perf_counter()
+    prob, desc = build_problem("frontal1m", 1)
+    E, N = prob.mesh.num_elements, prob.mesh.num_nodes
+    with Context(device=device, stop_mode=_lib.MAG_STOP_REL, tol=tol) as c:
+        c.upload_problem(prob)
+        c.run()
+        ms = []
+        for _ in range(reps):
+            c.run()
+            ms.append(c.stats()["ms_total"])
+        st = c.stats()
+        u = c.download()[0]
+        r = prob.f_in - c.apply_operator(u)  # f - K u on every DOF; the unknowns are where u is not prescribed
+        free = prob.u_known == 0
+        verify = float(np.linalg.norm(r[free]) / max(st["rhs_norm"], 1e-300))
+    mean_ms = sum(ms) / len(ms)
+    return {"workload": f"frontal1m: {desc}, {E} triangles, {N} nodes, left edge fixed, right edge ux=delta; CG stop=rel tol={tol:g}",
+            "elements": E, "nodes": N, "steps": reps, "ms_per_step": mean_ms, "value": E / (mean_ms * 1e-3), "unit": "elements/s",
+            "cg_kernel": int(st["cg_kernel"]), "edge_blocks": int(st["edge_blocks"]), "iterations": int(st["iterations"]),
+            "us_per_iteration": st["ms_cg"] * 1e3 / max(int(st["iterations"]), 1), "converged": int(st["converged"]),
+            "verify_rel_residual": verify, "phases_ms": {k: st[k] for k in ("ms_order", "ms_csr_symbolic", "ms_assemble",
+                                                                           "ms_bc", "ms_cg", "ms_post", "ms_total")},
+            "seconds": time.perf_counter() - t0}
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` started bare: run N ranks of this same command line under torch.distributed.run as a
     fresh CHILD process (this parent has made no GPU call and never will), stdout/stderr inherited so that rank 0's
@@ -324,6 +357,8 @@ def main():
                     help="fp32: the fp32 leg of BASELINE config 5's sweep (CG state and operator in fp32, dots in fp64; "
                          "streaming kernels; cannot meet the 1e-8 parity bar) -- the line then says dtype f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-unstructured", action="store_true",
+                    help="N = 1, default workload: skip the unstructured leg (whole solves of the 1M-triangle frontal-like mesh)")
     ap.add_argument("--no-hbm-resident", action="store_true",
                     help="N = 1: skip the HBM-resident leg (SpMV and iteration kernel timed on the 16M-triangle mesh)")
     ap.add_argument("--partition", default="weak", choices=["weak", "strong"],
@@ -617,6 +652,9 @@ def main():
         if world == 1 and not args.no_hbm_resident and args.workload != "multihole16m":
             ctx.close()  # its buffers are not needed any more; the 16M leg allocates ~5 GB of its own
             out["hbm_resident"] = hbm_resident_leg(local_rank, args.op_reps)
+        if world == 1 and not args.no_unstructured and args.workload == "hole1m":
+            ctx.close()  # (idempotent)
+            out["unstructured"] = unstructured_leg(local_rank, args.tol)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prob, iters, stop_mode, args.tol, args.cpu_sample_iters, args.cpu_threads)
             out["cpu_baseline"]["cores_available"] = os.cpu_count()

@@ -76,15 +76,17 @@ __device__ inline float ring_rcp<float>(float a) { return 1.0f / a; }
 template <class V2, class R>
 __device__ inline void fan_force(const V2 db, const V2 ub, const V2 dc, const V2 uc, R c0, R nu, R h, R &fx, R &fy)
 {
+    // (every multiply-add is written as the FMA it is: the rounding of the CG kernels is defined here, not by the compiler's
+    // contraction choices -- persist.hip is compiled with -ffp-contract=off)
     const R ba = db.y - dc.y, ga = dc.x - db.x;
-    const R twoA = db.x * dc.y - dc.x * db.y;
-    const R ex = dc.y * ub.x - db.y * uc.x;
-    const R ey = db.x * uc.y - dc.x * ub.y;
-    const R g = (dc.y * ub.y - dc.x * ub.x) + (db.x * uc.x - db.y * uc.y);
+    const R twoA = fma(db.x, dc.y, -(dc.x * db.y));
+    const R ex = fma(dc.y, ub.x, -(db.y * uc.x));
+    const R ey = fma(db.x, uc.y, -(dc.x * ub.y));
+    const R g = fma(dc.y, ub.y, -(dc.x * ub.x)) + fma(db.x, uc.x, -(db.y * uc.y));
     const R w = c0 * ring_rcp<R>(twoA);
-    const R sx = ex + nu * ey, sy = nu * ex + ey, tq = h * g;
-    fx += w * (ba * sx + ga * tq);
-    fy += w * (ga * sy + ba * tq);
+    const R sx = fma(nu, ey, ex), sy = fma(nu, ex, ey), tq = h * g;
+    fx = fma(w, fma(ba, sx, ga * tq), fx);
+    fy = fma(w, fma(ga, sy, ba * tq), fy);
 }
 
 // Ring walk without per-entry tests.  k_ring16 pads every row to the tile's row length with entries that repeat the
@@ -174,7 +176,7 @@ __device__ inline void ring_weights(const uint32_t (&w)[NW], int32_t nent, const
             const uint32_t e = entry(k);
             const double2 cxy = s_xy[e & IDMASK];
             const double2 d = make_double2(cxy.x - ca.x, cxy.y - ca.y);
-            const double twoA = pd.x * d.y - d.x * pd.y;
+            const double twoA = fma(pd.x, d.y, -(d.x * pd.y));
             if (!(e & 0x8000u)) wgt[k - 1] = c0 * fast_rcp(twoA);
             pd = d;
         }
@@ -185,12 +187,12 @@ template <class V2, class R>
 __device__ inline void fan_force_w(const V2 db, const V2 ub, const V2 dc, const V2 uc, R wt, R nu, R h, R &fx, R &fy)
 {
     const R ba = db.y - dc.y, ga = dc.x - db.x;
-    const R ex = dc.y * ub.x - db.y * uc.x;
-    const R ey = db.x * uc.y - dc.x * ub.y;
-    const R g = (dc.y * ub.y - dc.x * ub.x) + (db.x * uc.x - db.y * uc.y);
-    const R sx = ex + nu * ey, sy = nu * ex + ey, tq = h * g;
-    fx += wt * (ba * sx + ga * tq);
-    fy += wt * (ga * sy + ba * tq);
+    const R ex = fma(dc.y, ub.x, -(db.y * uc.x));
+    const R ey = fma(db.x, uc.y, -(dc.x * ub.y));
+    const R g = fma(dc.y, ub.y, -(dc.x * ub.x)) + fma(db.x, uc.x, -(db.y * uc.y));
+    const R sx = fma(nu, ey, ex), sy = fma(nu, ex, ey), tq = h * g;
+    fx = fma(wt, fma(ba, sx, ga * tq), fx);
+    fy = fma(wt, fma(ga, sy, ba * tq), fy);
 }
 
 template <int NW, int NC, uint32_t IDMASK = 0xfffu>
@@ -281,7 +283,7 @@ __device__ inline void ring_blocks(const uint32_t (&w)[NW], int32_t nent, XY &&x
             const bool closes = !(e & 0x8000u);
             const bool fold = k < NB || (e & IDMASK) == (entry(0) & IDMASK); // triangle NB only onto entry 0
             if (closes && fold) {
-                const double twoA = pd.x * d.y - d.x * pd.y;
+                const double twoA = fma(pd.x, d.y, -(d.x * pd.y));
                 const double wt = c0 * fast_rcp(twoA);
                 double b00 = 0.0, b10 = 0.0, b01 = 0.0, b11 = 0.0, c00 = 0.0, c10 = 0.0, c01 = 0.0, c11 = 0.0;
                 fan_force_w<double2, double>(pd, ex, d, z, wt, nu, h, b00, b10); // K_ab, first column
@@ -338,8 +340,8 @@ __device__ inline void ring_walk_blocks(const uint32_t (&w)[NW], const double2 *
         ul = u;
     }
     const double kap = folded ? 0.0 : kappa; // a fan closed inside the blocks: its antisymmetric parts cancel
-    fx += kap * (ul.y - u0.y);               // otherwise they telescope to kappa J (u_last - u_first)
-    fy -= kap * (ul.x - u0.x);
+    fx = fma(kap, ul.y - u0.y, fx);          // otherwise they telescope to kappa J (u_last - u_first)
+    fy = fma(-kap, ul.x - u0.x, fy);
 }
 
 // The same walk for rows with MORE than NB blocks (on-chip kernel, EBM == 2: gmsh-type meshes, where a quarter of the nodes
@@ -374,8 +376,8 @@ __device__ inline void ring_walk_blocks_ovf(const uint32_t (&w)[NW], const doubl
         ul = u;
     }
     const double kap = folded ? 0.0 : kappa;
-    fx += kap * (ul.y - u0.y);
-    fy -= kap * (ul.x - u0.x);
+    fx = fma(kap, ul.y - u0.y, fx);
+    fy = fma(-kap, ul.x - u0.x, fy);
     auto rec_of = [&](int32_t k) { return 2u * ((uint32_t)k < cnt ? off + (uint32_t)k : 0u); };
     auto apply = [&](const double2 a, const double2 b) {
         const double2 cp = s_p[(uint32_t)__double2loint(b.y)];
@@ -406,8 +408,20 @@ __device__ inline void ring_walk_blocks_ovf(const uint32_t (&w)[NW], const doubl
         }
     }
 #else
+    // MAG_PERSIST_OVF_UNCOND records are taken by EVERY wave, in the same basic block as the register blocks (their record
+    // reads issue alongside the six gathers; a wave none of whose lanes has that many reads the zero record): on a frontal
+    // mesh nearly every wave has a lane with a seventh neighbour.  The rest in a loop that is not unrolled.
+#ifndef MAG_PERSIST_OVF_UNCOND
+#define MAG_PERSIST_OVF_UNCOND 0
+#endif
+#pragma unroll
+    for (int32_t k = 0; k < MAG_PERSIST_OVF_UNCOND; ++k) {
+        const uint32_t i2 = rec_of(k);
+        const double2 a2 = pool[i2], b2 = pool[i2 + 1];
+        apply(a2, b2);
+    }
 #pragma clang loop unroll(disable)
-    for (int32_t k = 0; k < nmax; ++k) {
+    for (int32_t k = MAG_PERSIST_OVF_UNCOND; k < nmax; ++k) {
         const uint32_t i2 = rec_of(k);
         const double2 a2 = pool[i2], b2 = pool[i2 + 1];
         apply(a2, b2);

@@ -114,14 +114,23 @@ __device__ inline double wave_sum_dpp(double v)
                             __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+// a lane's double moved by a DPP control (lanes without a source read 0)
+template <int CTRL>
+__device__ inline double dpp_move_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
 // Wait for epoch `epoch`: every workgroup's partial record (two 16-byte pieces each, one per thread) and the q of this
 // thread's halo nodes, swept together until every tag matches; then the records are summed in one fixed two-level
 // order (chunks of eight workgroups, then the chunks) so that all workgroups hold the same bits.  grid <= 256.
 // Returns false when the spin budget runs out (some workgroup is not running): the timeout word is set for the host.
 template <int NH, bool EB = false>
 __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigned epoch, const int32_t (&hg)[NH],
-                                        double2 (&hq)[NH], double *s_S, double2 *s_rec, double *s_chunk,
-                                        unsigned long long *stamp = nullptr)
+                                        double2 (&hq)[NH], double *s_S, double2 *s_rec, double *s_chunk, double *s_part,
+                                        double (&Sx)[4], unsigned long long *stamp = nullptr)
 {
     const int tid = threadIdx.x;
     const int grid = gridDim.x;
@@ -194,6 +203,9 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
         }
         __builtin_amdgcn_s_sleep(1);
     }
+#ifdef MAG_PERSIST_STAMPS
+    if (stamp) stamp[4] = __builtin_amdgcn_s_memrealtime(); // this wave has its pieces
+#endif
     // every wave has everything?  One flag word per wave, ONE barrier (also: s_rec complete), one 32-byte read: the
     // library's __syncthreads_and is three barriers around an LDS atomic.
     {
@@ -204,6 +216,9 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
             __syncthreads();
             const uint4 f0 = ((const uint4 *)s_flag)[0], f1 = ((const uint4 *)s_flag)[1];
             done = (f0.x & f0.y & f0.z & f0.w & f1.x & f1.y & f1.z & f1.w) != 0u;
+#ifdef MAG_PERSIST_STAMPS
+            if (stamp) stamp[3] = __builtin_amdgcn_s_memrealtime(); // every wave of the workgroup has its pieces
+#endif
         } else {
             done = __syncthreads_and(wave_ok ? 1 : 0) != 0;
         }
@@ -252,8 +267,34 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
         if (tid == 0) __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return false;
     }
-    // every workgroup sums the same values in the same order (four records per lane, then the lanes): same bits
-    // everywhere.  Waves 0-3 take one of the four sums each (they sit on four different SIMDs): a quarter of the chain.
+    // every workgroup sums the same values in the same order: same bits everywhere.
+    // Round 4 (512 threads): one tree for the four sums, as in persist_block_sum.  Wave w takes records 32 w .. 32 w + 31, two
+    // lanes per record: an even lane loads the piece {sum 0, sum 1}, an odd lane {sum 2, sum 3} -- where level 1 of that tree
+    // leaves its values -- then level 2, two row shifts, the rows' partials through LDS, and EVERY wave adds the 32 partials of
+    // each sum itself (one 16-byte read, a four-step tree per row): the sums arrive in scalar registers of every wave, with
+    // one barrier and no broadcast through s_S (round 3: four loads per lane, a six-level tree, s_S, a second barrier).
+    if (blockDim.x == 512) {
+        const int l = tid & 63, m = 32 * (tid >> 6) + (l >> 1);
+        const double2 pc = m < grid ? s_rec[2 * m + (l & 1)] : make_double2(0.0, 0.0);
+        const bool two = (l & 2) != 0;
+        const double k2 = two ? pc.y : pc.x, s2 = two ? pc.x : pc.y;
+        double v = k2 + dpp_move_f64<0x4E>(s2);
+        v += dpp_move_f64<0x114>(v);
+        v += dpp_move_f64<0x118>(v);
+        if ((l & 15) >= 12) s_part[(((l & 1) << 1) | ((l >> 1) & 1)) * 32 + (tid >> 6) * 4 + (l >> 4)] = v;
+        __syncthreads();
+        const double2 pr = ((const double2 *)(s_part + (l >> 4) * 32))[l & 15];
+        double t = pr.x + pr.y;
+        t += dpp_move_f64<0x111>(t);
+        t += dpp_move_f64<0x112>(t);
+        t += dpp_move_f64<0x114>(t);
+        t += dpp_move_f64<0x118>(t);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            Sx[c] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t), 16 * c + 15),
+                                     __builtin_amdgcn_readlane(__double2loint(t), 16 * c + 15));
+        return true;
+    }
     if (tid < 256) {
         const int c = tid >> 6, lane = tid & 63;
         const double *rec = (const double *)s_rec; // record m: doubles 4 m .. 4 m + 3
@@ -268,6 +309,8 @@ __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigne
         if (lane == 0) s_S[c] = S;
     }
     __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Sx[c] = s_S[c];
     return true;
 }
 
@@ -609,44 +652,63 @@ __device__ inline void persist_comm_loop(const PersistParams &P, double *s_S, do
     }
 }
 
-// Workgroup totals of four partial sums for the two publishing threads (0 and 1): DPP wave trees, then the eight
-// waves in order.
+// Workgroup totals of four partial sums for the two publishing threads (0 and 1).
+// Round 4 (512 threads): the in-kernel stamps put 0.37 us into four full DPP wave trees and 0.49 us into the seven-step
+// cross-wave chain + the record's store -- a microsecond between the last walk and the record leaving, every iteration.
+// Now ONE tree serves the four sums: level 1 (lane pairs) halves the values a lane carries from four to two -- even lanes
+// keep sums 0 and 1, odd lanes 2 and 3 --, level 2 (pairs of pairs) from two to one, two row shifts finish a row of 16 lanes;
+// the four rows' partials of every wave go to LDS (s_part[sum][wave * 4 + row]: 32 per sum) and after the barrier wave 0
+// adds them with one 16-byte read and a four-step tree per row -- 7 + 5 additions on the critical path where there were
+// 24 + 7, a fixed order of additions as before (so every run gives the same bits; they are not round 3's bits).
+constexpr int kPersistPartDoubles = 128; // s_part: four sums x (8 waves x 4 rows)
 template <int THREADS>
-__device__ inline void persist_block_sum(double (&acc)[4], double *s_red)
+__device__ inline void persist_block_sum(double (&acc)[4], double *s_red, double *s_part,
+                                         [[maybe_unused]] unsigned long long *sub = nullptr)
 {
     constexpr int kPersistThreads = THREADS;
+    constexpr int NWV = kPersistThreads / 64;
+    if (NWV == 8) {
+        const int l = threadIdx.x & 63;
+        const bool odd = (l & 1) != 0, two = (l & 2) != 0;
+        // level 1, lanes l and l ^ 1 (quad_perm [1, 0, 3, 2]): an even lane keeps sums 0, 1 and hands over 2, 3; an odd lane the reverse
+        const double ka = odd ? acc[2] : acc[0], kb = odd ? acc[3] : acc[1];
+        const double sa = odd ? acc[0] : acc[2], sb = odd ? acc[1] : acc[3];
+        const double a = ka + dpp_move_f64<0xB1>(sa), b = kb + dpp_move_f64<0xB1>(sb);
+        // level 2, lanes l and l ^ 2 (quad_perm [2, 3, 0, 1]): lanes 0, 1 of a quad keep a, lanes 2, 3 keep b
+        const double k2 = two ? b : a, s2 = two ? a : b;
+        double v = k2 + dpp_move_f64<0x4E>(s2); // lane l of a quad now holds the quad's total of sum {0, 2, 1, 3}[l & 3]
+        v += dpp_move_f64<0x114>(v);            // row_shr:4
+        v += dpp_move_f64<0x118>(v);            // row_shr:8: lanes 12-15 of every row hold the row's totals
+        if ((l & 15) >= 12) s_part[(((l & 1) << 1) | ((l >> 1) & 1)) * 32 + (threadIdx.x >> 6) * 4 + (l >> 4)] = v;
+#ifdef MAG_PERSIST_STAMPS
+        if (sub) sub[0] = __builtin_amdgcn_s_memrealtime(); // wave trees done, at the barrier
+#endif
+        __syncthreads();
+#ifdef MAG_PERSIST_STAMPS
+        if (sub) sub[1] = __builtin_amdgcn_s_memrealtime(); // every wave has arrived
+#endif
+        if (threadIdx.x < 64) { // row c of wave 0 adds sum c's 32 partials: two per lane, then a tree over the row
+            const double2 pr = ((const double2 *)(s_part + (l >> 4) * 32))[l & 15];
+            double t = pr.x + pr.y;
+            t += dpp_move_f64<0x111>(t);
+            t += dpp_move_f64<0x112>(t);
+            t += dpp_move_f64<0x114>(t);
+            t += dpp_move_f64<0x118>(t);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                acc[c] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t), 16 * c + 15),
+                                          __builtin_amdgcn_readlane(__double2loint(t), 16 * c + 15));
+        }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] = wave_sum_dpp(acc[c]);
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) s_red[c * (kPersistThreads / 64) + (threadIdx.x >> 6)] = acc[c];
+        for (int c = 0; c < 4; ++c) s_red[c * NWV + (threadIdx.x >> 6)] = acc[c];
     }
     __syncthreads();
-    constexpr int NWV = kPersistThreads / 64;
-    if (NWV == 8) {
-        // The eight waves' partials of each sum, added in wave order from 0.0 -- by wave 0 as a chain ACROSS LANES: lane
-        // 8 c + i loads partial (c, i) (one coalesced LDS read) and step k hands the running sum from lane i = k - 1 to lane
-        // i = k (row_shr:1) -- seven dependent adds.  The two publishing threads used to add the 32 values themselves, and
-        // with every register of the edge-block kernel taken the compiler fed them one LDS load at a time: twelve exposed
-        // LDS round trips (~0.5 us) between the workgroup's barrier and the publication of its record, every iteration.
-        // Same order of additions, same bits.
-        if (threadIdx.x < 64) {
-            const int l = threadIdx.x;
-            const double v = l < 4 * NWV ? s_red[l] : 0.0;
-            double t = 0.0 + v;
-#pragma unroll
-            for (int k = 1; k < NWV; ++k) {
-                const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(t), 0x111, 0xf, 0xf, false); // row_shr:1
-                const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(t), 0x111, 0xf, 0xf, false);
-                const double prev = __hiloint2double(hi, lo);
-                if ((l & (NWV - 1)) == k) t = prev + v;
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                acc[c] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(t), c * NWV + NWV - 1),
-                                          __builtin_amdgcn_readlane(__double2loint(t), c * NWV + NWV - 1));
-        }
-    } else if (threadIdx.x < 2) {
+    if (threadIdx.x < 2) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             double t = 0.0;
@@ -726,7 +788,10 @@ constexpr int persist_npt(int threads) { return threads == 768 ? 3 : 4; } // nod
 #define MAG_PERSIST_STAMP_TID 0 // the lane that stamps (0: wave 0, the older wave of its SIMD; 256: wave 4, its partner)
 #endif
 [[maybe_unused]] constexpr int kStampFrom = 200, kStampTo = 1200;
-constexpr int kStampPhases = 8;
+// 0-6 the phases, 7 sweeps taken; detail (round 4): 8 wave trees of the sums, 9 the sums' barrier (waiting for the workgroup's
+// slowest wave), 10 cross-wave chain + record store, 11 the deferred x update, 12 after this wave's sweeps: waiting for the
+// workgroup's other waves, 13 record reduction + its barrier
+constexpr int kStampPhases = 14;
 
 // the per-slot flag bytes of a lane's nodes in ONE register (the on-chip kernel has none to spare)
 template <int N>
@@ -766,7 +831,8 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
     double *s_red = (double *)(s_rec + 2 * 256);
     double *s_S = s_red + 4 * (kPersistThreads / 64);
     double *s_chunk = s_S + 4;
-    [[maybe_unused]] double2 *s_pool = (double2 *)(s_chunk + 4 * 32); // overflow records (OV): two double2 each
+    double *s_part = s_chunk + 4 * 32; // persist_block_sum: the rows' partials of the four sums
+    [[maybe_unused]] double2 *s_pool = (double2 *)(s_part + kPersistPartDoubles); // overflow records (OV): two double2 each
     // slot s of this lane: local node s * THREADS + tid, in local tile (s * THREADS + tid) / B (a scalar: wave-uniform)
     auto t_loc = [&](int s) { return __builtin_amdgcn_readfirstlane((s * THREADS + tid) / B); };
     auto t_lt = [&](int s) { return (s * THREADS + tid) % B; };
@@ -823,7 +889,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             // bit 3 of the mask (k_mark_external): read through memory by a tile of ANOTHER workgroup, or by a sibling tile
             // that keeps its halo copies; a node only its siblings read through their LDS slots publishes nothing
             if (kPersistSiblings && !(mk & 8u)) flags.set(s, flags[s] & ~4u);
-            acc[0] += b.x * b.x + b.y * b.y;
+            acc[0] = fma(b.y, b.y, fma(b.x, b.x, acc[0]));
         } else {
             xy[lt] = make_double2(0.0, 0.0);
             flags.set(s, flags[s] | 3u);
@@ -1031,15 +1097,16 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         }
     }
     if (blockIdx.x == 0 && tid == 0) acc[1] = 1.0; // "p.q" > 0: alpha finite, multiplies q = 0
-    persist_block_sum<THREADS>(acc, s_red);
+    persist_block_sum<THREADS>(acc, s_red, s_part);
     int par = 0;
     unsigned epoch = tag0; // the tags of successive exchanges
     if (tid < 2) // the block sums are in every thread: two threads publish the record's two pieces
         put_granules(P.recg + 4 * (2 * ((int64_t)par * cgrid + blockIdx.x) + tid), epoch,
                      tid == 0 ? make_double2(acc[0], acc[1]) : make_double2(acc[2], acc[3]));
     double2 hq[NH]; // q of this thread's halo nodes
+    double Sx[4] = {0.0, 0.0, 0.0, 0.0}; // the four grid-wide sums as the single-GPU exchange hands them over (scalars)
     if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec)
-           : !persist_exchange<NH, EB>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk))
+           : !persist_exchange<NH, EB>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk, s_part, Sx))
         return;
 
     const double c0 = P.c0, nu = P.nu, h = P.h;
@@ -1111,7 +1178,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
 #ifdef MAG_PERSIST_STAMPS
     // the stamping lane's accumulators live in LDS (the spare words of s_chunk): the edge-block instantiation has no registers
     // for them, and a spilled register in the loop would be measured along with the phases
-    unsigned long long *stamp_sum = (unsigned long long *)(s_chunk + 16); // [kStampPhases], then `last`, then the count
+    unsigned long long *stamp_sum = (unsigned long long *)(s_chunk + 16); // [kStampPhases], then `last`, then the count, then scratch
     unsigned long long &stamp_last = stamp_sum[kStampPhases], &stamp_iters = stamp_sum[kStampPhases + 1];
     if (tid == MAG_PERSIST_STAMP_TID)
         for (int k = 0; k < kStampPhases + 2; ++k) stamp_sum[k] = 0;
@@ -1124,7 +1191,9 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             ++stamp_iters;
         }
 #endif
-        const double S0 = uniform_f64(s_S[0]), S1 = uniform_f64(s_S[1]), S2 = uniform_f64(s_S[2]), S3 = uniform_f64(s_S[3]);
+        // (single GPU: the exchange hands the sums over in scalar registers already)
+        const double S0 = MG ? uniform_f64(s_S[0]) : Sx[0], S1 = MG ? uniform_f64(s_S[1]) : Sx[1],
+                     S2 = MG ? uniform_f64(s_S[2]) : Sx[2], S3 = MG ? uniform_f64(s_S[3]) : Sx[3];
         if (j == 0) {
             bb = S0;
             target = uniform_f64(P.stop_mode == 2 ? P.tol * sqrt(bb) : P.tol);
@@ -1133,7 +1202,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         // alpha and beta before the stop test: their two division chains (~300 cycles, every wave, every iteration) then run
         // alongside the square root of the cost instead of behind it; on the way out they are simply not used
         const double alpha = uniform_f64(rr / S1);
-        const double beta = uniform_f64((rr + 2.0 * alpha * S2 + alpha * alpha * S3) / rr);
+        const double beta = uniform_f64(fma(alpha * alpha, S3, fma(2.0 * alpha, S2, rr)) / rr);
         cost = uniform_f64(P.stop_mode == 1 ? fabs(rr) : sqrt(rr));
         const long long it_done = j - 1;
         if (reporter && it_done >= 1 && it_done - 1 < P.hist_len) P.hist[it_done - 1] = cost;
@@ -1165,8 +1234,8 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
                 double2 *xy = t_xy(s), *pim = xy + capx, *xs = pim + cap + maxh;
                 const double2 po = pim[lt];
                 double2 xo = xs[lt];
-                xo.x += alpha * po.x;
-                xo.y += alpha * po.y;
+                xo.x = fma(alpha, po.x, xo.x);
+                xo.y = fma(alpha, po.y, xo.y);
                 xs[lt] = xo;
             }
         }
@@ -1176,10 +1245,11 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             const double2 po = pim[lt];
             const double2 qv = QL ? xy[lt] : q[s];
             double2 pn;
-            r[s].x += alpha * qv.x;
-            r[s].y += alpha * qv.y;
-            pn.x = -r[s].x + beta * po.x;
-            pn.y = -r[s].y + beta * po.y;
+            // (explicit FMAs: a halo copy of this node in another workgroup runs the same recurrence and must get the same bits)
+            r[s].x = fma(alpha, qv.x, r[s].x);
+            r[s].y = fma(alpha, qv.y, r[s].y);
+            pn.x = fma(beta, po.x, -r[s].x);
+            pn.y = fma(beta, po.y, -r[s].y);
             pim[lt] = pn;
         };
         // A workgroup whose node slots are all live (every one on the 1M mesh but the last) runs them as ONE basic block: the
@@ -1198,10 +1268,10 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             if (hg[e] != -1) {
                 double2 *hbase = smem + hloc[e]; // = tile base + position: coordinates at [B], p image at [cap + B], ...
                 double2 hrv = hbase[capx + cap], hpv = hbase[capx + B]; // the halo node's p lives in the p image itself
-                hrv.x += alpha * hq[e].x;
-                hrv.y += alpha * hq[e].y;
-                hpv.x = -hrv.x + beta * hpv.x;
-                hpv.y = -hrv.y + beta * hpv.y;
+                hrv.x = fma(alpha, hq[e].x, hrv.x);
+                hrv.y = fma(alpha, hq[e].y, hrv.y);
+                hpv.x = fma(beta, hpv.x, -hrv.x);
+                hpv.y = fma(beta, hpv.y, -hrv.y);
                 hbase[capx + cap] = hrv;
                 hbase[capx + B] = hpv;
             }
@@ -1276,22 +1346,36 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
 #endif
             if (MG && oslot[s] >= 0)
                 publish_q(P, par ^ 1, oslot[s], oreaders[s], epoch + 1, qn);
-            acc[0] += r[s].x * r[s].x + r[s].y * r[s].y;
-            acc[1] += pa.x * fx + pa.y * fy;
-            acc[2] += r[s].x * fx + r[s].y * fy;
-            acc[3] += fx * fx + fy * fy;
+            acc[0] = fma(r[s].y, r[s].y, fma(r[s].x, r[s].x, acc[0]));
+            acc[1] = fma(pa.y, fy, fma(pa.x, fx, acc[1]));
+            acc[2] = fma(r[s].y, fy, fma(r[s].x, fx, acc[2]));
+            acc[3] = fma(fy, fy, fma(fx, fx, acc[3]));
         }
 #if MAG_PERSIST_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
         MAG_STAMP(2) // ring walks of this wave's nodes, q published
-        persist_block_sum<THREADS>(acc, s_red);
+#ifdef MAG_PERSIST_STAMPS
+        unsigned long long *sub_ = stamp_sum + kStampPhases + 8;
+        persist_block_sum<THREADS>(acc, s_red, s_part, stamping ? sub_ : nullptr);
+#else
+        persist_block_sum<THREADS>(acc, s_red, s_part);
+#endif
         par ^= 1;
         ++epoch;
         ++j;
         if (tid < 2)
             put_granules(P.recg + 4 * (2 * ((int64_t)par * cgrid + blockIdx.x) + tid), epoch,
                          tid == 0 ? make_double2(acc[0], acc[1]) : make_double2(acc[2], acc[3]));
+#ifdef MAG_PERSIST_STAMPS
+        if (stamping) {
+            const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();
+            stamp_sum[8] += sub_[0] - stamp_last;
+            stamp_sum[9] += sub_[1] - sub_[0];
+            stamp_sum[10] += now_ - sub_[1];
+            sub_[2] = now_;
+        }
+#endif
         if (kPersistDeferX && !xnow) { // the deferred x += alpha p_{j-1}, in the shadow of the exchange's first wait
             const double ab = uniform_f64(alpha / beta);
             auto x_slot = [&](int s) {
@@ -1299,8 +1383,8 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
                 double2 *xy = t_xy(s), *pim = xy + capx, *xs = pim + cap + maxh;
                 const double2 pj = pim[lt], rv = r[s];
                 double2 xo = xs[lt];
-                xo.x += ab * (pj.x + rv.x);
-                xo.y += ab * (pj.y + rv.y);
+                xo.x = fma(ab, pj.x + rv.x, xo.x);
+                xo.y = fma(ab, pj.y + rv.y, xo.y);
                 xs[lt] = xo;
             };
             if (all_live) {
@@ -1312,22 +1396,28 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
                     if (flags[s] & 8) x_slot(s);
             }
         }
+#ifdef MAG_PERSIST_STAMPS
+        if (stamping) stamp_sum[11] += __builtin_amdgcn_s_memrealtime() - sub_[2];
+#endif
         MAG_STAMP(3) // workgroup sums (wave trees, barrier, eight waves in order) + record published
 #ifdef MAG_PERSIST_STAMPS
         unsigned long long *xs_ = stamp_sum + kStampPhases + 2; // (LDS as well: no stack object, no scratch in the diagnostic build)
-        if (stamping) xs_[0] = xs_[1] = xs_[2] = 0;
+        if (stamping) xs_[0] = xs_[1] = xs_[2] = xs_[3] = xs_[4] = 0;
         if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec)
-               : !persist_exchange<NH, EB>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk, stamping ? xs_ : nullptr))
+               : !persist_exchange<NH, EB>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk, s_part, Sx, stamping ? xs_ : nullptr))
             return;
         if (stamping) { // inside the exchange: wait before the first sweep / sweeps until complete / record reduction
             stamp_sum[4] += xs_[0] - stamp_last;
             stamp_sum[5] += xs_[1] - xs_[0];
-            stamp_sum[6] += __builtin_amdgcn_s_memrealtime() - xs_[1];
+            const unsigned long long end_ = __builtin_amdgcn_s_memrealtime();
+            stamp_sum[6] += end_ - xs_[1];
             stamp_sum[7] += xs_[2]; // sweeps taken
+            stamp_sum[12] += xs_[3] - xs_[4];
+            stamp_sum[13] += end_ - xs_[3];
         }
 #else
         if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec)
-               : !persist_exchange<NH, EB>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk))
+               : !persist_exchange<NH, EB>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk, s_part, Sx))
             return;
 #endif
     }
@@ -1538,7 +1628,7 @@ size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh, int threads, int 
     const size_t tiles = (size_t)persist_tiles_per_wg(B, threads);
     const size_t capx = eb_mode == 2 ? (size_t)B : (size_t)cap; // with overflow blocks the first area holds q of the owned nodes only
     return tiles * (capx + (size_t)cap + (size_t)maxh + (size_t)B) * 16 + 2 * 256 * 16 +
-           (4 * ((size_t)threads / 64) + 4 + 4 * 32) * 8 + 16 + (eb_mode == 2 ? 32 * (size_t)pool : 0);
+           (4 * ((size_t)threads / 64) + 4 + 4 * 32 + kPersistPartDoubles) * 8 + 16 + (eb_mode == 2 ? 32 * (size_t)pool : 0);
 }
 
 template <int THREADS>
@@ -1686,7 +1776,7 @@ __global__ void __launch_bounds__(256) k_edge_blocks_ovf(const PersistParams P, 
         const uint32_t id = entry(k) & 0xfffu;
         const double2 cxy = xy_of(id);
         const double2 d = make_double2(cxy.x - ca.x, cxy.y - ca.y);
-        const double twoA = pd.x * d.y - d.x * pd.y;
+        const double twoA = fma(pd.x, d.y, -(d.x * pd.y));
         const double wt = P.c0 * fast_rcp(twoA);
         double b00 = 0.0, b10 = 0.0, b01 = 0.0, b11 = 0.0, c00 = 0.0, c10 = 0.0, c01 = 0.0, c11 = 0.0;
         fan_force_w<double2, double>(pd, ex, d, z, wt, P.nu, P.h, b00, b10); // K_ab, first column

@@ -131,14 +131,20 @@ void hilbert_keys(const double *xy, int64_t N, const double *bbox4, uint32_t *ke
     k_hilbert_keys<<<blocks_for(N, 256), 256, 0, s>>>((const double2 *)xy, N, bbox4, keys, ids);
 }
 
+// cdeg (may be null): triangles per node in caller numbering (k_count_degree) -> deg in the new numbering, so that
+// k_incidence_keys need not count them again with atomics
 __global__ void __launch_bounds__(256) k_apply_order(const uint32_t *perm, const double2 *xy, const uint8_t *u_known,
                                                      int64_t N, int32_t *iperm, double2 *xyP, uint8_t *maskP,
-                                                     int32_t *known_count)
+                                                     int32_t *known_count, const int32_t *cdeg, int32_t *deg)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const uint32_t o = perm[i];
     iperm[o] = (int32_t)i;
+    if (cdeg) {
+        deg[i] = cdeg[o];
+        if (i == 0) deg[N] = 0;
+    }
     xyP[i] = xy[o];
     const int kx = u_known[2 * (int64_t)o] ? 1 : 0, ky = u_known[2 * (int64_t)o + 1] ? 1 : 0;
     maskP[i] = (uint8_t)(kx | (ky << 1));
@@ -146,10 +152,82 @@ __global__ void __launch_bounds__(256) k_apply_order(const uint32_t *perm, const
 }
 
 void apply_order(const uint32_t *perm, const double *xy, const uint8_t *u_known, int64_t N, int32_t *iperm,
-                 double *xyP, uint8_t *maskP, int32_t *known_count, hipStream_t s)
+                 double *xyP, uint8_t *maskP, int32_t *known_count, const int32_t *cdeg, int32_t *deg, hipStream_t s)
 {
     k_apply_order<<<blocks_for(N, 256), 256, 0, s>>>(perm, (const double2 *)xy, u_known, N, iperm, (double2 *)xyP,
-                                                     maskP, known_count);
+                                                     maskP, known_count, cdeg, deg);
+}
+
+// ---- within-tile order by valence (round 4) ----
+// The tiles are runs of B nodes of the Hilbert order; INSIDE a tile the order is free.  The on-chip CG kernel keeps six edge
+// blocks per node in registers and a node's further blocks in an LDS pool, and a wave pays for the longest row among its
+// 64 lanes -- with the plain Hilbert order nearly every wave of a gmsh-type mesh holds a node of valence 7 (a quarter of
+// the nodes) and most hold one of valence 8.  So each tile is stably partitioned by class = min(7, max(0, triangles - 6)):
+// the nodes with six triangles or fewer first, in their Hilbert order, then those with seven, eight, ...; the result is then
+// rotated by a tile-dependent quarter (below), so that the long rows of a workgroup's four tiles fall on different waves.  A tile
+// whose nodes all have class 0 -- every tile of a structured mesh -- keeps its order: the permutation is the identity there.
+// cdeg: triangles per node in CALLER numbering (k_count_degree).  One workgroup of B threads per tile.
+__global__ void __launch_bounds__(256) k_count_degree(const int32_t *conn, int64_t n3, int64_t N, int32_t *cdeg)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n3) return;
+    const int32_t n = conn[k];
+    if (n >= 0 && (int64_t)n < N) atomicAdd(&cdeg[n], 1); // (an index out of range is reported by k_incidence_keys)
+}
+
+template <int B>
+__global__ void __launch_bounds__(B) k_tile_valence_partition(const uint32_t *perm_in, const int32_t *cdeg, int64_t N,
+                                                              uint32_t *perm_out)
+{
+    constexpr int NW = B / 64, NC = 8;
+    __shared__ int32_t s_cnt[NC][NW];
+    const int32_t t = blockIdx.x, l = threadIdx.x, wave = l >> 6;
+    const int64_t i = (int64_t)t * B + l;
+    const bool valid = i < N;
+    const uint32_t o = valid ? perm_in[i] : 0u;
+    int32_t c = 0;
+    if (valid) {
+        const int32_t d = cdeg[o] - 6;
+        c = d < 0 ? 0 : (d > NC - 1 ? NC - 1 : d);
+    }
+    int32_t rank_in_wave = 0;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        const unsigned long long m = __ballot(valid && c == k);
+        if (c == k) rank_in_wave = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if ((l & 63) == 0) s_cnt[k][wave] = __popcll(m);
+    }
+    __syncthreads();
+    int32_t base = 0;
+    for (int k = 0; k < NC; ++k)
+        for (int w = 0; w < NW; ++w)
+            if (k < c || (k == c && w < wave)) base += s_cnt[k][w];
+    // ... and the partitioned order is ROTATED by a quarter of the tile per tile index: the long rows at its end fall on waves
+    // 6-7, 0-1, 2-3, 4-5 for the four tiles a workgroup of the on-chip kernel holds -- every wave gets one tile's long rows.
+    // (a whole tile only: the last, partial tile keeps the plain partition; a tile without long rows is rotated all the same
+    // unless EVERY class is 0 -- the structured meshes' tiles stay as the Hilbert order left them)
+    int32_t pos = base + rank_in_wave;
+    const bool whole = (int64_t)(t + 1) * B <= N;
+    int32_t nz = 0;
+    for (int w = 0; w < NW; ++w) nz += s_cnt[0][w];
+    if (whole && nz != B) pos = (pos + (B / 4) * (t & 3)) & (B - 1);
+    if (valid) perm_out[(int64_t)t * B + pos] = o;
+}
+
+void count_degree(const int32_t *conn, int64_t E, int64_t N, int32_t *cdeg, hipStream_t s)
+{
+    k_count_degree<<<blocks_for(3 * E, 256), 256, 0, s>>>(conn, 3 * E, N, cdeg);
+}
+
+void tile_valence_partition(const uint32_t *perm_in, const int32_t *cdeg, int64_t N, int32_t B, int32_t T, uint32_t *perm_out,
+                            hipStream_t s)
+{
+    if (B == 256)
+        k_tile_valence_partition<256><<<T, 256, 0, s>>>(perm_in, cdeg, N, perm_out);
+    else if (B == 512)
+        k_tile_valence_partition<512><<<T, 512, 0, s>>>(perm_in, cdeg, N, perm_out);
+    else
+        (void)hipMemcpyAsync(perm_out, perm_in, 4 * (size_t)N, hipMemcpyDeviceToDevice, s);
 }
 
 // ----------------------------------------------------------- incidence ---
@@ -167,7 +245,7 @@ __global__ void __launch_bounds__(256) k_incidence_keys(const int32_t *conn, int
     const int32_t g = iperm[n];
     keys[k] = (uint32_t)g;
     vals[k] = (uint32_t)k;
-    atomicAdd(&deg[g], 1);
+    if (deg) atomicAdd(&deg[g], 1); // (null: already counted in caller numbering and carried over by k_apply_order)
 }
 
 void incidence_keys(const int32_t *conn, int64_t E, const int32_t *iperm, int64_t N, uint32_t *keys, uint32_t *vals,

@@ -19,7 +19,7 @@ if [ "$FILE" = "exact.hip" ]; then
     OBJS=${OBJS/build\/exact.o/build\/exact_$NAME.o}
 else
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I../../include -I. -Wall -Wno-unused-result $FLAGS \
-        -mllvm -amdgpu-sched-strategy=$SCHED -c persist.hip -o build/persist_$NAME.o
+        -ffp-contract=off -mllvm -amdgpu-sched-strategy=$SCHED -c persist.hip -o build/persist_$NAME.o
     OBJS=${OBJS/build\/persist.o/build\/persist_$NAME.o}
 fi
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../ab/libmagnetite_hip_$NAME.so $OBJS -ldl -Wl,-rpath,/opt/rocm/lib

@@ -64,6 +64,11 @@ def main():
             st = run(workload, threads, f)
             rows = [[int(v) for v in l.split(",")] for l in open(f) if l.strip()]
             rows = [r for r in rows if r[-1] > 0]
+            detail = None
+            if rows and len(rows[0]) >= 15:  # round 4's stamps: six detail intervals behind the eight phase words
+                names = ["sums_wave_trees", "sums_barrier_wait_for_slowest_wave", "sums_chain_and_record_store", "deferred_x_update",
+                         "after_own_sweeps_wait_for_other_waves", "record_reduction_and_its_barrier"]
+                detail = {nm: sum(r[8 + k] / r[-1] * 0.01 for r in rows) / len(rows) for k, nm in enumerate(names)}
             n = len(rows)
             per_wg = [[r[k] / r[-1] * 0.01 for k in range(7)] for r in rows]  # us per iteration
             mean = [sum(w[k] for w in per_wg) / n for k in range(7)]
@@ -77,7 +82,7 @@ def main():
                  "phases_us_mean_over_workgroups": dict(zip(PHASES, mean)),
                  "phases_us_min": dict(zip(PHASES, lo)), "phases_us_max": dict(zip(PHASES, hi)),
                  "phases_sum_us": sum(mean), "sweeps_per_iteration": sweeps,
-                 "compute_us": sum(mean[:4]), "exchange_us": sum(mean[4:])}
+                 "compute_us": sum(mean[:4]), "exchange_us": sum(mean[4:]), "detail_us_mean": detail}
             print(json.dumps(d), flush=True)
             out["runs"].append(d)
     json.dump(out, open(out_path, "w"), indent=1)

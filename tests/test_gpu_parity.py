@@ -1125,7 +1125,9 @@ def test_on_chip_edge_blocks_with_overflow_match_the_oracle_and_the_triangle_wal
     for key in ("u", "f", "stress"):  # (a relative stop at 1e-9 leaves the reactions and stresses at ~1e-8)
         assert rel(out[key], ref[key]) <= (TOL_U if key == "u" or not kw else 1e-7), (case, key)
     # (the reference's stop rule runs to round-off, where the iteration count wobbles with the order of the sums)
-    assert rel(out["u"], walk["u"]) <= 1e-9 and abs(out["iterations"] - walk["iterations"]) <= max(3, ref["iterations"] // 50), case
+    # (... and two solves stopped at a relative 1e-9 differ by about that much)
+    assert rel(out["u"], walk["u"]) <= (1e-8 if kw else 1e-9), case
+    assert abs(out["iterations"] - walk["iterations"]) <= max(3, ref["iterations"] // 50), case
     assert np.array_equal(out["u"], again["u"])              # bitwise reproducible
     if case == "structured_forced":  # the same blocks as the register-only instantiation: the same solution to rounding
         monkeypatch.delenv("MAG_TUNE_PERSIST_FORCE_OVERFLOW")
