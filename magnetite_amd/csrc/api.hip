@@ -144,7 +144,7 @@ struct mag_ctx {
     double best_cost = 0.0;   // argmin's best_param bookkeeping, as the CG phase that just ran reported it
     long long best_iter = 0;
     bool persist_timed_out = false, exchange_timed_out = false;
-    bool rhs_folded = false; // the assembly of this run wrote b = 0.0 + f itself (k_assemble_fan)
+    bool b_from_order = false; // the ordering phase of this run wrote b = 0.0 + f for every node (k_apply_order)
     int edge_blocks = 0; // instantiation of the on-chip kernel of the last run: 1 edge blocks, 2 with overflow records (mag_stats.edge_blocks)
     // streaming kernels across GPUs: the per-iteration exchange through the device inboxes (k_stream_exchange) instead of
     // an all-reduce; si_failed: a wait ran out once, this context uses the all-reduce from then on
@@ -276,6 +276,7 @@ int ensure_order(mag_ctx *ctx)
     HIPCHK(ctx->iperm.reserve(4 * (size_t)N));
     HIPCHK(ctx->xyP.reserve(16 * (size_t)N));
     HIPCHK(ctx->maskP.reserve((size_t)N));
+    HIPCHK(ctx->bP.reserve(16 * (size_t)N)); // written by apply_order (b = 0.0 + f), completed after the assembly
     HIPCHK(ctx->deg.reserve(4 * ((size_t)N + 1)));
     HIPCHK(ctx->inc_off.reserve(4 * ((size_t)N + 1)));
     HIPCHK(ctx->inc.reserve(4 * 3 * (size_t)E));
@@ -311,7 +312,9 @@ int ensure_order(mag_ctx *ctx)
     HIPCHK(hipMemsetAsync(errflag, 0, 8, s)); // {error flag, prescribed-displacement count}
     magk::apply_order(ctx->perm.as<uint32_t>(), ctx->xy.as<double>(), ctx->uknown.as<uint8_t>(), N,
                       ctx->iperm.as<int32_t>(), ctx->xyP.as<double>(), ctx->maskP.as<uint8_t>(), errflag + 1,
-                      counted ? ctx->inc_off.as<int32_t>() : nullptr, ctx->deg.as<int32_t>(), s);
+                      counted ? ctx->inc_off.as<int32_t>() : nullptr, ctx->deg.as<int32_t>(), ctx->fin.as<double>(),
+                      ctx->bP.as<double>(), s);
+    ctx->b_from_order = true;
 
     if (!counted) HIPCHK(hipMemsetAsync(ctx->deg.p, 0, 4 * ((size_t)N + 1), s));
     magk::incidence_keys(ctx->conn.as<int32_t>(), E, ctx->iperm.as<int32_t>(), N, ctx->sK0.as<uint32_t>(),
@@ -632,14 +635,9 @@ int element_phase(mag_ctx *ctx)
 // with LDS staging (k_assemble_tiles).  MAG_TUNE_ASSEMBLY=rows: one thread per block straight from global memory
 // (round 1's kernel); MAG_TUNE_KE_BUFFER=1: the two-step form (K_e for every element, then a gather over the sorted
 // pairs).  All three are bit-identical.
-int gather_phase(mag_ctx *ctx, bool want_rhs = false)
+int gather_phase(mag_ctx *ctx)
 {
     const char *how = getenv("MAG_TUNE_ASSEMBLY");
-    // the fan kernel can write the right-hand side of the rows without a prescribed column on its way (round 4); the rows
-    // that have one are flagged by the pattern kernel (bc_touch_ready) and redone from K by rhs_touched
-    const char *nf = getenv("MAG_TUNE_RHS_FOLD");
-    const bool rhs_fold = want_rhs && ctx->bc_touch_ready && !(nf && atoi(nf) == 0);
-    ctx->rhs_folded = false;
     if (getenv("MAG_TUNE_KE_BUFFER")) {
         if (int rc = element_phase(ctx)) return rc;
         magk::assemble_gather(ctx->pk1.as<uint64_t>(), ctx->pv1.as<uint32_t>(), ctx->seg_start.as<int32_t>(), ctx->nb,
@@ -656,11 +654,8 @@ int gather_phase(mag_ctx *ctx, bool want_rhs = false)
                                      ctx->ell_asm.as<uint32_t>(), ctx->ell_pos.as<uint16_t>(),
                                      ctx->inc_off.as<int32_t>(), ctx->inc.as<uint32_t>(),
                                      ctx->conn.as<int32_t>(), ctx->xy.as<double>(), ctx->N, ctx->B, ctx->T, ctx->cap,
-                                     ctx->nu, ctx->youngs, ctx->thick, ctx->kval.as<double>(),
-                                     rhs_fold ? ctx->uknown.as<uint8_t>() : nullptr, rhs_fold ? ctx->fin.as<double>() : nullptr,
-                                     rhs_fold ? ctx->bP.as<double>() : nullptr, ctx->stream)) {
-        // assembled from the CG tiles (coordinates and caller ids staged in LDS); b = 0.0 + f written along the way
-        ctx->rhs_folded = rhs_fold;
+                                     ctx->nu, ctx->youngs, ctx->thick, ctx->kval.as<double>(), ctx->stream)) {
+        // assembled from the CG tiles (coordinates and caller ids staged in LDS)
     } else {
         magk::assemble_tiles(ctx->bcol.as<int32_t>(), ctx->bptr.as<int32_t>(), ctx->inc_off.as<int32_t>(),
                              ctx->inc.as<uint32_t>(), ctx->perm.as<uint32_t>(), ctx->conn.as<int32_t>(),
@@ -1927,12 +1922,14 @@ int mag_run(mag_ctx *ctx)
         HIPCHK(hipEventRecord(ctx->ev[2], s));
         HIPCHK(hipEventRecord(ctx->ev[3], s)); // K_e is evaluated inside the row assembly (ms_element stays 0)
         if (ctx->opt.verbose) printf("info: building total stiffness matrix...\n");
-        if (int rc = gather_phase(ctx, true)) return rc;
+        if (int rc = gather_phase(ctx)) return rc;
         ctx->have_csr = true;
         HIPCHK(hipEventRecord(ctx->ev[4], s));
         if (ctx->opt.verbose) printf("info: setting up system...\n");
         HIPCHK(ctx->bc_touch.reserve((size_t)N + 16));
-        if (ctx->rhs_folded)
+        // the ordering phase has written b = 0.0 + f for every node (apply_order); only the rows with a prescribed column need
+        // K, and the pattern kernel has flagged them (bc_touch_ready); otherwise the full pass
+        if (ctx->b_from_order && ctx->bc_touch_ready && !getenv("MAG_TUNE_RHS_FULL"))
             magk::rhs_touched(ctx->bptr.as<int32_t>(), ctx->bcol.as<int32_t>(), ctx->kval.as<double>(),
                               ctx->uknown.as<uint8_t>(), ctx->uin.as<double>(), ctx->fin.as<double>(),
                               ctx->perm.as<uint32_t>(), ctx->bc_touch.as<uint8_t>(), N, ctx->bP.as<double>(), s);

@@ -589,8 +589,7 @@ __global__ void __launch_bounds__(kFanThreads) k_assemble_fan(const int32_t *bco
                                                               const uint16_t *ell_pos, const int32_t *inc_off,
                                                               const uint32_t *inc, const int32_t *conn, const double2 *xy,
                                                               int64_t N, int32_t cap, int32_t img_pieces, int32_t segs,
-                                                              int32_t six, double nu, double youngs, double thick, double *kval,
-                                                              const uint8_t *u_known, const double2 *f_in, double2 *bP)
+                                                              int32_t six, double nu, double youngs, double thick, double *kval)
 {
     extern __shared__ __attribute__((aligned(16))) double2 s_asm[];
     double2 *s_xy = s_asm;                                   // [cap] coordinates of the tile's owned + halo nodes
@@ -637,14 +636,9 @@ __global__ void __launch_bounds__(kFanThreads) k_assemble_fan(const int32_t *bco
     // for its own loads on the spot and for the previous pass's stores with them, ~3 us per pass for 0.4 us of
     // arithmetic) -- and they are collected after the evaluation, BEFORE this pass's stores are issued: the counter is
     // in-order, so a wait placed after the stores would wait for their acknowledgements too.
-    // (round 4) The right-hand side rides along: a row WITHOUT a prescribed column has b = 0.0 + f (solver.rs:427-432 with
-    // an empty known part), 0 on a prescribed DOF, and the node's caller id is at hand here -- its two forces and its two
-    // flag bytes are fetched with the row pointers and b is written in Hilbert order by the node's first lane.  Rows next to
-    // prescribed nodes (the pattern kernel's `touch` flags; O(sqrt N) of them) are redone from K afterwards by k_rhs_touched.
     struct Row {
         int32_t i, p, pe;
-        uint32_t w, pos, uk;
-        double2 f;
+        uint32_t w, pos;
     };
     const int32_t nvalid = (int32_t)((N - (int64_t)t * B) < (int64_t)B ? (N - (int64_t)t * B) : (int64_t)B);
     const int32_t llast = (lend < nvalid ? lend : nvalid) - 1; // last node of this segment that exists
@@ -669,12 +663,6 @@ __global__ void __launch_bounds__(kFanThreads) k_assemble_fan(const int32_t *bco
             r.pe = bptr[r.i + 1];
             r.w = table[(int64_t)kk * B + lcl];
             r.pos = ptable[(int64_t)kk * B + lcl];
-            r.uk = 0;
-            r.f = make_double2(0.0, 0.0);
-            if (bP) {
-                r.uk = ((const uint16_t *)u_known)[r.i];
-                r.f = f_in[r.i];
-            }
             return r;
         };
         Row cur = fetch(lfirst + lnode);
@@ -739,8 +727,6 @@ __global__ void __launch_bounds__(kFanThreads) k_assemble_fan(const int32_t *bco
             }
             if (rowfan && k < 4) ((double *)(stage + (k >> 1) * cnt + (int)((pos >> 8) & 15u)))[k & 1] = dsum;
             if (k == 0 && lane_used) hdr[nw] = make_int2(p, rowfan ? cnt : 0);
-            if (bP && k == 0 && valid)
-                bP[(int64_t)t * B + l] = make_double2((cur.uk & 0xffu) ? 0.0 : 0.0 + cur.f.x, (cur.uk >> 8) ? 0.0 : 0.0 + cur.f.y);
             wave_lds_sync();
             // ---- the next pass's words are here by now (requested before the evaluation); collect them, then store
             __builtin_amdgcn_s_waitcnt(0x0f70); // vmcnt(0)
@@ -780,11 +766,6 @@ __global__ void __launch_bounds__(kFanThreads) k_assemble_fan(const int32_t *bco
     } else if (llast >= lfirst) { // a tile without a single triangle: whatever rows its nodes have go to the workgroup
         for (int32_t l = lfirst + lane; l <= llast; l += kFanThreads) {
             const int32_t i = s_cid[l];
-            if (bP) {
-                const uint32_t uk = ((const uint16_t *)u_known)[i];
-                const double2 f = f_in[i];
-                bP[(int64_t)t * B + l] = make_double2((uk & 0xffu) ? 0.0 : 0.0 + f.x, (uk >> 8) ? 0.0 : 0.0 + f.y);
-            }
             if (bptr[i + 1] - bptr[i] > 0) {
                 s_big[l] = i;
                 any_big = true;
@@ -841,8 +822,7 @@ bool assemble_ctiles(const int32_t *bcol, const int32_t *bptr, const uint32_t *p
                      const double *halo_xy, const int32_t *tile_hoff, const int32_t *tile_deg, const int64_t *tile_off,
                      const uint32_t *ell_asm, const uint16_t *ell_pos, const int32_t *inc_off, const uint32_t *inc,
                      const int32_t *conn, const double *xy, int64_t N, int32_t B, int32_t T, int32_t cap, double nu,
-                     double youngs, double thick, double *kval, const uint8_t *u_known, const double *f_in, double *bP,
-                     hipStream_t s)
+                     double youngs, double thick, double *kval, hipStream_t s)
 {
     const size_t lds = assemble_ctiles_lds(B, cap);
     if ((B != 256 && B != 512) || cap > 4096 || lds > 64 * 1024) return false; // 12-bit local ids; the image fits the LDS
@@ -857,13 +837,11 @@ bool assemble_ctiles(const int32_t *bcol, const int32_t *bptr, const uint32_t *p
     if (B == 256)
         k_assemble_fan<256><<<T * segs, kFanThreads, lds, s>>>(
             bcol, bptr, perm, (const double2 *)xyP, (const double2 *)halo_xy, tile_hoff, tile_deg, tile_off, ell_asm,
-            ell_pos, inc_off, inc, conn, (const double2 *)xy, N, cap, img, segs, six, nu, youngs, thick, kval, u_known,
-            (const double2 *)f_in, (double2 *)bP);
+            ell_pos, inc_off, inc, conn, (const double2 *)xy, N, cap, img, segs, six, nu, youngs, thick, kval);
     else
         k_assemble_fan<512><<<T * segs, kFanThreads, lds, s>>>(
             bcol, bptr, perm, (const double2 *)xyP, (const double2 *)halo_xy, tile_hoff, tile_deg, tile_off, ell_asm,
-            ell_pos, inc_off, inc, conn, (const double2 *)xy, N, cap, img, segs, six, nu, youngs, thick, kval, u_known,
-            (const double2 *)f_in, (double2 *)bP);
+            ell_pos, inc_off, inc, conn, (const double2 *)xy, N, cap, img, segs, six, nu, youngs, thick, kval);
     return true;
 }
 
@@ -949,12 +927,13 @@ __global__ void __launch_bounds__(256) k_mark_bc_rows(const int32_t *bptr, const
 // inputs are gathered -- scattered 8-byte stores through the permutation cost more than the whole row sums).
 __global__ void __launch_bounds__(256) k_rhs_from_csr(const int32_t *bptr, const int32_t *bcol, const double *kval,
                                                       const uint8_t *u_known, const double *u_in, const double *f_in,
-                                                      const uint32_t *perm, const uint8_t *touch, int64_t N, double2 *bP)
+                                                      const uint32_t *perm, const uint8_t *touch, bool hilbert_flags,
+                                                      int64_t N, double2 *bP)
 {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= N) return;
     const int64_t i = perm[g];
-    const bool t = touch[i] != 0;
+    const bool t = touch[hilbert_flags ? g : i] != 0;
     double2 v;
     // a row without a prescribed column: rhs_row's sum stays at its 0.0, i.e. 0.0 + f (the same bits, -0.0 included)
     v.x = u_known[2 * i] ? 0.0 : (t ? rhs_row(bptr, bcol, kval, u_known, u_in, f_in, 2 * i) : 0.0 + f_in[2 * i]);
@@ -962,20 +941,55 @@ __global__ void __launch_bounds__(256) k_rhs_from_csr(const int32_t *bptr, const
     bP[g] = v;
 }
 
-// The rows the assembly could not finish on its own: those with a prescribed column (k_assemble_fan has written b = 0.0 + f
-// everywhere; the pattern kernel's `touch` flags say where K_fk u_k is not empty).  One thread per node, the others leave at once.
+// (round 4) The right-hand side of a row WITHOUT a prescribed column is b = 0.0 + f (solver.rs:427-432 with an empty known
+// part; 0 on a prescribed DOF): the ordering phase writes that for every node while it gathers the node's other data by the
+// permutation (symbolic.hip, k_apply_order).  Only the rows that have a prescribed column need K: the pattern kernel flags
+// them in Hilbert order (one coalesced byte per thread here; O(sqrt N) rows do the work, the others leave at once).  Round 3's
+// kernel gathered flag, mask and forces of EVERY node by caller id: 17.6 us at 1M triangles, three times the row sums.
 __global__ void __launch_bounds__(256) k_rhs_touched(const int32_t *bptr, const int32_t *bcol, const double *kval,
                                                      const uint8_t *u_known, const double *u_in, const double *f_in,
                                                      const uint32_t *perm, const uint8_t *touch, int64_t N, double2 *bP)
 {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= N) return;
+    if (g >= N || !touch[g]) return;
     const int64_t i = perm[g];
-    if (!touch[i]) return;
-    double2 v;
-    v.x = u_known[2 * i] ? 0.0 : rhs_row(bptr, bcol, kval, u_known, u_in, f_in, 2 * i);
-    v.y = u_known[2 * i + 1] ? 0.0 : rhs_row(bptr, bcol, kval, u_known, u_in, f_in, 2 * i + 1);
-    bP[g] = v;
+    // Both rows of the node, eight block columns at a time: the columns, then their flags, then the values behind the
+    // prescribed ones are each fetched together (the few threads that work here are latency chains: with rhs_row's one
+    // column at a time the kernel took 14 us at 1M triangles for ~1500 rows); the sums run in rhs_row's order -- ascending
+    // column, x then y, every term (K u) * -1.0 -- and end with + f.
+    const int32_t p = bptr[i], nb = bptr[i + 1] - p;
+    const double *row0 = kval + 4 * (int64_t)p, *row1 = row0 + 2 * (int64_t)nb;
+    double s0 = 0.0, s1 = 0.0;
+    for (int32_t k0 = 0; k0 < nb; k0 += 8) {
+        int32_t col[8];
+        uint32_t uk[8];
+        double2 u[8], a0[8], a1[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) col[k] = k0 + k < nb ? bcol[p + k0 + k] : -1;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) uk[k] = col[k] >= 0 ? ((const uint16_t *)u_known)[col[k]] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (uk[k]) {
+                u[k] = ((const double2 *)u_in)[col[k]];
+                a0[k] = ((const double2 *)row0)[k0 + k];
+                a1[k] = ((const double2 *)row1)[k0 + k];
+            }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (uk[k] & 0xffu) {
+                s0 += (a0[k].x * u[k].x) * -1.0;
+                s1 += (a1[k].x * u[k].x) * -1.0;
+            }
+            if (uk[k] >> 8) {
+                s0 += (a0[k].y * u[k].y) * -1.0;
+                s1 += (a1[k].y * u[k].y) * -1.0;
+            }
+        }
+    }
+    const uint32_t own = ((const uint16_t *)u_known)[i];
+    const double2 f = ((const double2 *)f_in)[i];
+    bP[g] = make_double2((own & 0xffu) ? 0.0 : s0 + f.x, (own >> 8) ? 0.0 : s1 + f.y);
 }
 
 void rhs_touched(const int32_t *bptr, const int32_t *bcol, const double *kval, const uint8_t *u_known, const double *u_in,
@@ -993,7 +1007,9 @@ void rhs_from_csr(const int32_t *bptr, const int32_t *bcol, const double *kval, 
         (void)hipMemsetAsync(touch, 0, (size_t)N, s);
         k_mark_bc_rows<<<blocks_for(N, 256), 256, 0, s>>>(bptr, bcol, u_known, N, touch);
     }
-    k_rhs_from_csr<<<blocks_for(N, 256), 256, 0, s>>>(bptr, bcol, kval, u_known, u_in, f_in, perm, touch, N, (double2 *)bP);
+    // (flags from the pattern kernel are in Hilbert order, those marked here in caller numbering)
+    k_rhs_from_csr<<<blocks_for(N, 256), 256, 0, s>>>(bptr, bcol, kval, u_known, u_in, f_in, perm, touch, touch_ready, N,
+                                                      (double2 *)bP);
 }
 
 __global__ void __launch_bounds__(256) k_rhs_compact(const int32_t *bptr, const int32_t *bcol, const double *kval,

@@ -34,7 +34,8 @@ void bbox(const double *xy, int64_t N, double *scratch, double *bbox4, hipStream
 void hilbert_keys(const double *xy, int64_t N, const double *bbox4, uint32_t *keys, uint32_t *ids, hipStream_t s);
 // perm = new->old (sorted ids).  Writes iperm (old->new), xyP[new] and maskP[new] = known_x | known_y<<1
 void apply_order(const uint32_t *perm, const double *xy, const uint8_t *u_known, int64_t N, int32_t *iperm,
-                 double *xyP, uint8_t *maskP, int32_t *known_count, const int32_t *cdeg, int32_t *deg, hipStream_t s);
+                 double *xyP, uint8_t *maskP, int32_t *known_count, const int32_t *cdeg, int32_t *deg, const double *f_in,
+                 double *bP, hipStream_t s);
 // per element corner k=3e+c: keys[k] = iperm[conn[k]], vals[k] = k, deg[key]++ ; out-of-range conn sets *err
 void incidence_keys(const int32_t *conn, int64_t E, const int32_t *iperm, int64_t N, uint32_t *keys,
                     uint32_t *vals, int32_t *deg, int32_t *err, hipStream_t s);
@@ -125,10 +126,9 @@ bool assemble_ctiles(const int32_t *bcol, const int32_t *bptr, const uint32_t *p
                      const double *halo_xy, const int32_t *tile_hoff, const int32_t *tile_deg, const int64_t *tile_off,
                      const uint32_t *ell_asm, const uint16_t *ell_pos, const int32_t *inc_off, const uint32_t *inc,
                      const int32_t *conn, const double *xy, int64_t N, int32_t B, int32_t T, int32_t cap, double nu,
-                     double youngs, double thick, double *kval, const uint8_t *u_known, const double *f_in, double *bP,
-                     hipStream_t s);
-// bP != null: the kernel also writes b = 0.0 + f (0 on prescribed DOFs) for every node, Hilbert order -- the right-hand side
-// of every row without a prescribed column; rhs_touched then redoes the rows that have one (the pattern kernel's flags)
+                     double youngs, double thick, double *kval, hipStream_t s);
+// apply_order has written b = 0.0 + f (0 on prescribed DOFs) for every node; this redoes the rows with a prescribed column
+// (touch: the pattern kernel's flags, Hilbert order)
 void rhs_touched(const int32_t *bptr, const int32_t *bcol, const double *kval, const uint8_t *u_known, const double *u_in,
                  const double *f_in, const uint32_t *perm, const uint8_t *touch, int64_t N, double *bP, hipStream_t s);
 // solver.rs:365-404,427-432: b[row] = sum_{known cols, ascending} -(K*u) + f  (0 on prescribed rows),

@@ -818,6 +818,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
     constexpr int kPersistThreads = THREADS;
     constexpr int NPT = persist_npt(THREADS);
     constexpr bool EB = EBM != 0, OV = EBM == 2;
+    constexpr int SB = NPT * THREADS / B - 1; // bias of the workgroup-relative ring entries, in tile images (see the remap below)
     extern __shared__ __attribute__((aligned(16))) double2 smem[];
     const int tid = threadIdx.x;
     const int cap = P.cap, maxh = P.maxh;
@@ -906,8 +907,10 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
 #pragma unroll
         for (int k = 0; k < kPersistRegs; ++k)
             if (k < deg[s]) w[s][k] = P.ell16[ell_off[s] + (int64_t)k * B];
-        // Ring entries become slots RELATIVE TO THE WORKGROUP'S TILES: entry = 3 * tile_words + (owner tile - this tile) *
-        // tile_words + position, read through this tile's base moved down by 3 * tile_words (15 bits: up to seven tile images).
+        // Ring entries become slots RELATIVE TO THE WORKGROUP'S TILES: entry = SB * tile_words + (owner tile - this tile) *
+        // tile_words + position, read through this tile's base moved down by SB * tile_words; SB = tiles per workgroup - 1 (3
+        // with 512-node tiles, 7 with 256-node ones: the first tile's references reach SB tiles up, the last one's SB down;
+        // 2 SB + 1 tile images fit the 15 bits whenever the tiles fit the LDS).
         // A reference to a node that a SIBLING tile of this workgroup owns then points straight at the owner's slots (its
         // coordinates, its p), and the reader keeps no halo copy of it: no q to fetch for it, no r / p to advance -- about half
         // of a workgroup's halo entries when its tiles are consecutive in the Hilbert order.  Only for tiles whose rows all sit
@@ -923,11 +926,11 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             auto remap = [&](uint32_t e) -> uint32_t {
                 if (e == 0xffffu) return e;
                 const uint32_t lid = e & 0xfffu;
-                uint32_t slot = (uint32_t)(3 * tile_words) + lid;
+                uint32_t slot = (uint32_t)(SB * tile_words) + lid;
                 if (short_rows && lid >= (uint32_t)B) {
                     const int32_t g = P.halo_g[tm.hoff + (int32_t)(lid - B)];
                     const int32_t ot = g / B, ol = ot - t_first;
-                    if (ol >= 0 && ol < P.tiles_per_wg && ot < t_end) slot = (uint32_t)((3 + ol - l) * tile_words + (g - ot * B));
+                    if (ol >= 0 && ol < P.tiles_per_wg && ot < t_end) slot = (uint32_t)((SB + ol - l) * tile_words + (g - ot * B));
                 }
                 return slot | (e & 0x8000u);
             };
@@ -937,13 +940,13 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             if (OV) {
                 // this node's blocks beyond the registers: k_edge_blocks_ovf left them at ovf_off[node] + j with the ring
                 // entry they multiply (tile-local); they move into the workgroup's pool with that entry rewritten like the others
-                // (record 0 of the pool is a zero block on slot `3 * tile_words` -- local node 0 of the reading tile --: what a
+                // (record 0 of the pool is a zero block on slot `SB * tile_words` -- local node 0 of the reading tile --: what a
                 // lane with fewer records than its wave's longest row reads in the steps it has nothing for)
                 int32_t cnt = 0;
                 uint32_t off = 0;
                 if (tid == 0 && s == 0) {
                     s_pool[0] = make_double2(0.0, 0.0);
-                    s_pool[1] = make_double2(0.0, __hiloint2double(0, 3 * tile_words));
+                    s_pool[1] = make_double2(0.0, __hiloint2double(0, SB * tile_words));
                 }
                 if (nd < P.N) {
                     constexpr int NBk = kPersistBlockEntries;
@@ -1151,7 +1154,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             const double2 *xy = t_xy(s);
             const int32_t nent = __builtin_amdgcn_readfirstlane(ent[s]);
             if (nent > 0)
-                ring_weights<kPersistRegs, NCW, 0x7fffu>(w[s], nent, xy - 3 * tile_words, xy[t_lt(s)], c0,
+                ring_weights<kPersistRegs, NCW, 0x7fffu>(w[s], nent, xy - SB * tile_words, xy[t_lt(s)], c0,
                                                          *reinterpret_cast<double(*)[NCW]>(&wgt[s][0]));
         }
     }
@@ -1306,6 +1309,15 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             // profiles/r03_persist_ab.txt (q0-q16): none better.
             if (((tid >> 8) & 1) && s >= NPT / 2) __builtin_amdgcn_s_setprio(1);
 #endif
+#ifndef MAG_PERSIST_OVF_PRIO
+#define MAG_PERSIST_OVF_PRIO 2 // frontal1m: 6.39 (off), 6.31 (1), 6.30 (2) us per iteration
+#endif
+#if MAG_PERSIST_OVF_PRIO
+            // (OV) a wave that carries this slot's long rows -- the valence partition gives every wave one such slot --
+            // takes priority for it: it is the one the workgroup's sums will wait for
+            if (OV && ovmax[s] > 0) __builtin_amdgcn_s_setprio(MAG_PERSIST_OVF_PRIO);
+            else if (OV && !(((tid >> 8) & 1) && s >= NPT / 2)) __builtin_amdgcn_s_setprio(0);
+#endif
             if (!(flags[s] & 8)) continue;
             const int lt = t_lt(s);
             const double2 *xy = t_xy(s), *pim = xy + capx;
@@ -1314,22 +1326,22 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             {
                 const int32_t nent = __builtin_amdgcn_readfirstlane(ent[s]); // one tile per wave: a scalar
                 if (nent > 0) { // entries are biased slots relative to this tile (see the remap at the top)
-                    const uint32_t toff = (uint32_t)(3 * tile_words);
+                    const uint32_t toff = (uint32_t)(SB * tile_words);
                     if (OV) {
                         const uint32_t oc = (ovpk[s >> 1] >> (16 * (s & 1))) & 0xffffu;
-                        ring_walk_blocks_ovf<kPersistRegs, NB, 0x7fffu>(w[s], pim - 3 * tile_words, pa, kappa, (flags[s] & 32u) != 0,
+                        ring_walk_blocks_ovf<kPersistRegs, NB, 0x7fffu>(w[s], pim - SB * tile_words, pa, kappa, (flags[s] & 32u) != 0,
                                                                         *reinterpret_cast<const double(*)[3 * NB]>(&wgt[s][0]), s_pool,
                                                                         oc & 0xfffu, oc >> 12, ovmax[s], fx, fy);
                     } else if (BLOCKS)
-                        ring_walk_blocks<kPersistRegs, NB, 0x7fffu>(w[s], pim - 3 * tile_words, pa, kappa, (flags[s] & 32u) != 0,
+                        ring_walk_blocks<kPersistRegs, NB, 0x7fffu>(w[s], pim - SB * tile_words, pa, kappa, (flags[s] & 32u) != 0,
                                                                     *reinterpret_cast<const double(*)[3 * NB]>(&wgt[s][0]), fx, fy);
                     else if (CACHED)
-                        ring_walk_cached<kPersistRegs, NCW, 0x7fffu>(w[s], P.ell16 + ell_off[s], B, nent, xy - 3 * tile_words, pim - 3 * tile_words,
+                        ring_walk_cached<kPersistRegs, NCW, 0x7fffu>(w[s], P.ell16 + ell_off[s], B, nent, xy - SB * tile_words, pim - SB * tile_words,
                                                                      ca, pa, c0, nu, h, *reinterpret_cast<const double(*)[NCW]>(&wgt[s][0]),
                                                                      fx, fy, toff);
                     else
                         ring_walk_uniform<kPersistRegs, kPersistBlock, kPersistBlock2, 0x7fffu>(
-                            w[s], P.ell16 + ell_off[s], B, nent, xy - 3 * tile_words, pim - 3 * tile_words, ca, pa, c0, nu, h, fx, fy,
+                            w[s], P.ell16 + ell_off[s], B, nent, xy - SB * tile_words, pim - SB * tile_words, ca, pa, c0, nu, h, fx, fy,
                             toff);
                 }
             }

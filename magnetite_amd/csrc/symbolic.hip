@@ -6,6 +6,8 @@
 //   * node-block CSR pattern of K in the caller's numbering, ascending columns
 #include <cstring>
 
+#include <type_traits>
+
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -132,10 +134,14 @@ void hilbert_keys(const double *xy, int64_t N, const double *bbox4, uint32_t *ke
 }
 
 // cdeg (may be null): triangles per node in caller numbering (k_count_degree) -> deg in the new numbering, so that
-// k_incidence_keys need not count them again with atomics
+// k_incidence_keys need not count them again with atomics.
+// f_in / bP (may be null): the right-hand side of a row without a prescribed column, b = 0.0 + f (0 on a prescribed DOF;
+// solver.rs:427-432 with nothing known next to the row), written here in the new order while the node's other data are
+// gathered anyway; the rows that do have a prescribed column are redone from K later (exact.hip, k_rhs_touched).
 __global__ void __launch_bounds__(256) k_apply_order(const uint32_t *perm, const double2 *xy, const uint8_t *u_known,
                                                      int64_t N, int32_t *iperm, double2 *xyP, uint8_t *maskP,
-                                                     int32_t *known_count, const int32_t *cdeg, int32_t *deg)
+                                                     int32_t *known_count, const int32_t *cdeg, int32_t *deg,
+                                                     const double2 *f_in, double2 *bP)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
@@ -148,14 +154,19 @@ __global__ void __launch_bounds__(256) k_apply_order(const uint32_t *perm, const
     xyP[i] = xy[o];
     const int kx = u_known[2 * (int64_t)o] ? 1 : 0, ky = u_known[2 * (int64_t)o + 1] ? 1 : 0;
     maskP[i] = (uint8_t)(kx | (ky << 1));
+    if (bP) {
+        const double2 f = f_in[o];
+        bP[i] = make_double2(kx ? 0.0 : 0.0 + f.x, ky ? 0.0 : 0.0 + f.y);
+    }
     if (kx + ky) atomicAdd(known_count, kx + ky); // prescribed displacements (solver.rs:370)
 }
 
 void apply_order(const uint32_t *perm, const double *xy, const uint8_t *u_known, int64_t N, int32_t *iperm,
-                 double *xyP, uint8_t *maskP, int32_t *known_count, const int32_t *cdeg, int32_t *deg, hipStream_t s)
+                 double *xyP, uint8_t *maskP, int32_t *known_count, const int32_t *cdeg, int32_t *deg, const double *f_in,
+                 double *bP, hipStream_t s)
 {
     k_apply_order<<<blocks_for(N, 256), 256, 0, s>>>(perm, (const double2 *)xy, u_known, N, iperm, (double2 *)xyP,
-                                                     maskP, known_count, cdeg, deg);
+                                                     maskP, known_count, cdeg, deg, (const double2 *)f_in, (double2 *)bP);
 }
 
 // ---- within-tile order by valence (round 4) ----
@@ -570,9 +581,15 @@ __global__ void __launch_bounds__(256) k_ring16(const int32_t *tile_deg, const i
             single = false;
             if (row_info) row_info[(int64_t)t * B + l] = 0;
         } else if (d > 0) {
-            uint32_t pr[kRingMaxDeg];
-            uint16_t out[2 * kRingMaxDeg];
-            for (int k = 0; k < d; ++k) pr[k] = row[(int64_t)k * B];
+            // (MAXD: the arrays live in registers and every loop over them is unrolled to their size -- rows of up to eight
+            // triangles, all but a few per cent even of an unstructured mesh, take the small instantiation: the kernel went
+            // from 132 to ~45 us at 1M triangles)
+            auto ring_row = [&](auto maxd_c) {
+            constexpr int MAXD = decltype(maxd_c)::value;
+            uint32_t pr[MAXD];
+            uint16_t out[2 * MAXD];
+#pragma unroll
+            for (int k = 0; k < MAXD; ++k) pr[k] = k < d ? row[(int64_t)k * B] : 0xffffffffu;
             uint32_t used = 0;
             int n = 0, remaining = d;
             while (remaining > 0) {
@@ -628,6 +645,11 @@ __global__ void __launch_bounds__(256) k_ring16(const int32_t *tile_deg, const i
                 const uint32_t lo = 2 * k < n ? out[2 * k] : pad, hi = 2 * k + 1 < n ? out[2 * k + 1] : pad;
                 row[(int64_t)k * B] = lo | (hi << 16);
             }
+            }; // ring_row
+            if (d <= 8)
+                ring_row(std::integral_constant<int, 8>{});
+            else
+                ring_row(std::integral_constant<int, kRingMaxDeg>{});
         } else {
             for (int k = 0; k < td; ++k) row[(int64_t)k * B] = 0x80008000u; // no triangles: slot 0, break, throughout
             if (row_info) row_info[(int64_t)t * B + l] = 0x80u; // no entries, no blocks
@@ -735,7 +757,7 @@ __global__ void __launch_bounds__(256) k_pattern_rows(const int32_t *inc_off, co
     const int64_t i = perm[g];
     if (local && !local[i]) {
         if (!FILL) out[i] = 0;
-        if (FILL && touch) touch[i] = 0;
+        if (FILL && touch) touch[g] = 0;
         return;
     }
     int32_t cols[kRowCap];
@@ -791,7 +813,7 @@ __global__ void __launch_bounds__(256) k_pattern_rows(const int32_t *inc_off, co
 #pragma unroll
             for (int k = 0; k < kRowCap; ++k)
                 if (k < n) t |= ((const uint16_t *)u_known)[cols[k]];
-            touch[i] = t ? 1 : 0;
+            touch[g] = t ? 1 : 0; // (Hilbert order: the right-hand side's kernel reads one coalesced byte per thread)
         }
     } else {
         out[i] = over ? 0 : n;

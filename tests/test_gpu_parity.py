@@ -1021,7 +1021,7 @@ def _disc(m, rings):
     return meshgen.Mesh(np.array(pts), np.array(tri, dtype=np.int32), f"disc{m}x{rings}")
 
 
-@pytest.mark.parametrize("case", ["plate", "hole_perturbed", "clockwise", "disc3", "disc4", "disc5", "tile256"])
+@pytest.mark.parametrize("case", ["plate", "hole_perturbed", "clockwise", "disc3", "disc4", "disc5", "tile256", "tile256_k8"])
 def test_on_chip_edge_blocks_match_the_oracle_and_the_triangle_walk(built, case, monkeypatch):
     """Meshes whose nodes all carry ONE fan of at most six entries run the on-chip kernel's edge-block instantiation
     (mag_stats.edge_blocks): symmetric 2 x 2 blocks per ring entry built once per solve by k_edge_blocks, antisymmetric
@@ -1038,6 +1038,9 @@ def test_on_chip_edge_blocks_match_the_oracle_and_the_triangle_walk(built, case,
         p = meshgen.config_fixed_left_pull_right(meshgen.clockwise(meshgen.plate_with_holes(64)))
     elif case == "tile256":
         p, tile = meshgen.config_fixed_left_pull_right(meshgen.plate_with_holes(96)), 256
+    elif case == "tile256_k8":  # eight 256-node tiles per workgroup: sibling slots reach seven tile images up and down
+        monkeypatch.setenv("MAG_TUNE_PERSIST_K", "8")
+        p, tile = meshgen.config_fixed_left_pull_right(meshgen.shuffle(meshgen.plate_with_holes(110), 5)), 256
     else:
         m = int(case[-1])
         mesh = meshgen.perturb(_disc(m, 24), 0.1, m)
