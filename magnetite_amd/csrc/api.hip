@@ -504,7 +504,8 @@ int ensure_order(mag_ctx *ctx)
         ctx->persist_maxh = ((max_halo + 3) / 4) * 4;
         if (kmax > 0 && k >= 1 && k >= kmin && k <= kmax && (tiles_max + k - 1) / k <= 256 && // the gather holds 256
             (int64_t)k * max_halo <= 2 * pthreads && // a workgroup's halo entries are dealt out two per thread
-            magk::persist_lds_bytes(B, ctx->cap, ctx->persist_maxh, pthreads) + 256 <= 160 * 1024) { // + the static 256 bytes
+            magk::persist_lds_bytes(B, ctx->cap, ctx->persist_maxh, pthreads, 0, 0, mg) + 256 <= 160 * 1024 && // + the static 256 bytes
+            (!mg || ctx->n_iface < (1 << 24))) { // (interface slots are kept in 24 bits on the chip)
             ctx->persist = true;
             ctx->persist_k = k;
             ctx->persist_grid = (ctx->t1 - ctx->t0 + k - 1) / k;
@@ -1329,9 +1330,11 @@ int cg_phase_persist(mag_ctx *ctx)
     // if every workgroup's records fit the LDS its more compact layout leaves free (mode 2); the triangle walk otherwise.
     int eb_mode = 0;
     const int64_t npad = (int64_t)ctx->T * ctx->B;
-    // (several ranks: the ordering phase is replicated, so every rank reads the same flag; the multi-GPU edge-block
-    // instantiation is behind MAG_TUNE_PERSIST_MG_BLOCKS until a node has measured it)
-    if ((!mg || getenv("MAG_TUNE_PERSIST_MG_BLOCKS")) && !getenv("MAG_TUNE_PERSIST_TRIANGLES")) {
+    // (several ranks: the ordering phase is replicated, so every rank reads the same flag.  The multi-GPU edge-block
+    // instantiation is the default since round 4 -- two ranks sharing the GPU at four tiles per workgroup: 9.1 against 10.7 us
+    // per iteration, fixture parity on both ranks --; MAG_TUNE_PERSIST_MG_BLOCKS=0 keeps the triangle walk across ranks)
+    const char *mgb = getenv("MAG_TUNE_PERSIST_MG_BLOCKS");
+    if ((!mg || !(mgb && atoi(mgb) == 0)) && !getenv("MAG_TUNE_PERSIST_TRIANGLES")) {
         int32_t fan_flags = 3;
         HIPCHK(hipMemcpyAsync(&fan_flags, ctx->tile_rdeg.as<int32_t>() + 2 * (size_t)ctx->T, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -1379,11 +1382,15 @@ int cg_phase_persist(mag_ctx *ctx)
     }
     magk::persist_launch(P, ctx->B, grid + P.comm_wg, magk::persist_threads(), eb_mode, s);
     if (stamps) {
-        std::vector<unsigned long long> h((size_t)magk::persist_stamp_words() * (size_t)grid);
+        // (several ranks: one file per rank, "<name>.<rank>"; with an exchange workgroup its row follows the compute workgroups')
+        const int rows = grid + P.comm_wg;
+        std::vector<unsigned long long> h((size_t)magk::persist_stamp_words() * (size_t)rows);
         HIPCHK(hipMemcpyAsync(h.data(), ctx->pstamps.p, 8 * h.size(), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        if (FILE *f = fopen(getenv("MAG_TUNE_PERSIST_STAMPS"), "w")) {
-            for (int g = 0; g < grid; ++g) {
+        std::string fname = getenv("MAG_TUNE_PERSIST_STAMPS");
+        if (mg) fname += "." + std::to_string(ctx->comm.rank);
+        if (FILE *f = fopen(fname.c_str(), "w")) {
+            for (int g = 0; g < rows; ++g) {
                 for (int k = 0; k < magk::persist_stamp_words(); ++k)
                     fprintf(f, "%s%llu", k ? "," : "", h[(size_t)g * magk::persist_stamp_words() + k]);
                 fprintf(f, "\n");

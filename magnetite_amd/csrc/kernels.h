@@ -398,7 +398,7 @@ void stream_exchange_launch(double *buf, int32_t g_all, int32_t n_iface, int32_t
 int persist_threads(); // workgroup shape of the on-chip kernel: 512 (x 4 nodes per lane) or 768 (x 3); MAG_TUNE_PERSIST_THREADS
 int persist_tiles_per_wg(int32_t B, int threads); // tiles one workgroup keeps on chip (0: tile size not supported)
 // eb_mode: 0 triangle walk, 1 edge blocks (every row a fan of <= 6 blocks), 2 edge blocks with `pool` overflow records in LDS
-size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh, int threads, int eb_mode = 0, int32_t pool = 0);
+size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh, int threads, int eb_mode = 0, int32_t pool = 0, bool mg = false);
 // MG kernel when nranks > 1; eb_mode as above (the host decides from ring16's flags and the overflow limits)
 void persist_launch(const PersistParams &P, int32_t B, int32_t grid, int threads, int eb_mode, hipStream_t s);
 int persist_block_entries(); // block entries per node of that instantiation

@@ -114,6 +114,12 @@ __device__ inline double wave_sum_dpp(double v)
                             __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+[[maybe_unused]] constexpr int kStampFrom = 200, kStampTo = 1200;
+// 0-6 the phases, 7 sweeps taken; detail (round 4): 8 wave trees of the sums, 9 the sums' barrier (waiting for the workgroup's
+// slowest wave), 10 cross-wave chain + record store, 11 the deferred x update, 12 after this wave's sweeps: waiting for the
+// workgroup's other waves, 13 record reduction + its barrier
+constexpr int kStampPhases = 14;
+
 // a lane's double moved by a DPP control (lanes without a source read 0)
 template <int CTRL>
 __device__ inline double dpp_move_f64(double v)
@@ -375,7 +381,8 @@ __device__ inline void publish_q(const PersistParams &P, int par, int32_t slot, 
 // same bits.
 template <int NH>
 __device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsigned tag, const int32_t (&hg)[NH],
-                                           double2 (&hq)[NH], double *s_S, double2 *s_rec)
+                                           double2 (&hq)[NH], double *s_S, double2 *s_rec,
+                                           [[maybe_unused]] unsigned long long *stamp = nullptr)
 {
     const int tid = threadIdx.x;
     const int grid = (int)gridDim.x - P.comm_wg, R = P.nranks; // compute workgroups
@@ -436,6 +443,9 @@ __device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsi
 #endif
     __builtin_amdgcn_s_sleep(MAG_PERSIST_SLEEP_MG);
     __builtin_amdgcn_s_sleep(MAG_PERSIST_SLEEP_MG);
+#ifdef MAG_PERSIST_STAMPS
+    if (stamp) stamp[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (lead) {
         // (1) this rank's records (and this workgroup's own halo values)
         bool have_rec = tid >= 2 * grid, done = false;
@@ -510,7 +520,9 @@ __device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsi
     // ranks on one GPU); otherwise workgroup 0 republishes the total on the device
     const bool direct = P.comm_wg != 0;
     bool have_g = tid >= (direct ? 2 * R : 2), done = false;
+    [[maybe_unused]] unsigned sweeps_ = 0;
     for (unsigned spins = 0; spins < P.spin_limit; ++spins) {
+        ++sweeps_;
         bool ok = true;
         if (!have_g) {
             double2 v;
@@ -532,6 +544,12 @@ __device__ inline bool persist_exchange_mg(const PersistParams &P, int par, unsi
         __builtin_amdgcn_s_sleep(2);
     }
     if (!done) return fail();
+#ifdef MAG_PERSIST_STAMPS
+    if (stamp) { // (a workgroup barrier per sweep here: no wave finishes before the others)
+        stamp[1] = stamp[3] = stamp[4] = __builtin_amdgcn_s_memrealtime();
+        stamp[2] = sweeps_;
+    }
+#endif
     if (tid < 4) {
         const double *rec = (const double *)s_rec;
         double t = rec[tid];
@@ -574,7 +592,18 @@ __device__ inline void persist_comm_loop(const PersistParams &P, double *s_S, do
     int par = 0;
     unsigned tag = P.tag_base + 1u;
     double target = P.tol, bb = 0.0;
+#ifdef MAG_PERSIST_STAMPS
+    // phases of the exchange workgroup, iterations [kStampFrom, kStampTo): waiting for this rank's records / summing them and
+    // storing the rank's sum into every inbox / waiting for every rank's sum / the rest (its row of PersistParams::stamps is
+    // the one behind the compute workgroups': words 0-3, word kStampPhases the iterations counted)
+    unsigned long long cs_[4] = {0, 0, 0, 0}, cn_ = 0;
+#endif
     for (long long j = 0;; ++j) {
+#ifdef MAG_PERSIST_STAMPS
+        const bool cst_ = tid == 0 && j >= kStampFrom && j < kStampTo;
+        unsigned long long ct0_ = 0, ct1_ = 0, ct2_ = 0, ct3_ = 0;
+        if (cst_) ct0_ = __builtin_amdgcn_s_memrealtime();
+#endif
         const unsigned long long *recb = P.recg + 8 * (int64_t)par * grid;
         // (1) this rank's records
         bool have_rec = tid >= 2 * grid, done = false;
@@ -592,6 +621,9 @@ __device__ inline void persist_comm_loop(const PersistParams &P, double *s_S, do
             if (gave_up(spins)) break;
         }
         if (!done) return fail();
+#ifdef MAG_PERSIST_STAMPS
+        if (cst_) ct1_ = __builtin_amdgcn_s_memrealtime();
+#endif
         if (tid < 64) {
             double S[4] = {0.0, 0.0, 0.0, 0.0};
             for (int m = tid; m < grid; m += 64) {
@@ -609,6 +641,9 @@ __device__ inline void persist_comm_loop(const PersistParams &P, double *s_S, do
                                  (tid & 1) == 0 ? make_double2(S[0], S[1]) : make_double2(S[2], S[3]));
         }
         __syncthreads();
+#ifdef MAG_PERSIST_STAMPS
+        if (cst_) ct2_ = __builtin_amdgcn_s_memrealtime();
+#endif
         // (3) every rank's sum
         bool have_w = tid >= 2 * R;
         done = false;
@@ -627,6 +662,15 @@ __device__ inline void persist_comm_loop(const PersistParams &P, double *s_S, do
             __builtin_amdgcn_s_sleep(1);
         }
         if (!done) return fail();
+#ifdef MAG_PERSIST_STAMPS
+        if (cst_) {
+            ct3_ = __builtin_amdgcn_s_memrealtime();
+            cs_[0] += ct1_ - ct0_;
+            cs_[1] += ct2_ - ct1_;
+            cs_[2] += ct3_ - ct2_;
+            ++cn_;
+        }
+#endif
         if (tid < 4) { // (4) rank order: the same bits on every rank
             const double *rec = (const double *)s_rec;
             double t = 0.0;
@@ -644,8 +688,16 @@ __device__ inline void persist_comm_loop(const PersistParams &P, double *s_S, do
         const double cost = P.stop_mode == 1 ? fabs(rr) : sqrt(rr);
         const long long it_done = j - 1;
         if ((j == 0 && bb == 0.0) || (it_done >= 1 && cost <= target) || !(fabs(rr) <= 1.79769313486231570e308) ||
-            it_done >= P.max_iter)
+            it_done >= P.max_iter) {
+#ifdef MAG_PERSIST_STAMPS
+            if (tid == 0 && P.stamps) {
+                unsigned long long *o = P.stamps + (size_t)grid * (kStampPhases + 1);
+                for (int k = 0; k < 3; ++k) o[k] = cs_[k];
+                o[kStampPhases] = cn_;
+            }
+#endif
             return;
+        }
         __syncthreads(); // s_S and s_rec are rewritten by the next epoch
         par ^= 1;
         ++tag;
@@ -787,11 +839,7 @@ constexpr int persist_npt(int threads) { return threads == 768 ? 3 : 4; } // nod
 #ifndef MAG_PERSIST_STAMP_TID
 #define MAG_PERSIST_STAMP_TID 0 // the lane that stamps (0: wave 0, the older wave of its SIMD; 256: wave 4, its partner)
 #endif
-[[maybe_unused]] constexpr int kStampFrom = 200, kStampTo = 1200;
-// 0-6 the phases, 7 sweeps taken; detail (round 4): 8 wave trees of the sums, 9 the sums' barrier (waiting for the workgroup's
-// slowest wave), 10 cross-wave chain + record store, 11 the deferred x update, 12 after this wave's sweeps: waiting for the
-// workgroup's other waves, 13 record reduction + its barrier
-constexpr int kStampPhases = 14;
+
 
 // the per-slot flag bytes of a lane's nodes in ONE register (the on-chip kernel has none to spare)
 template <int N>
@@ -846,8 +894,11 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
     }
     constexpr int NH = kPersistNh; // halo entries per thread: the workgroup's halo nodes are dealt out over ALL threads
     const unsigned tag0 = (MG ? P.tag_base : 0u) + 1u; // tag of epoch e: tag0 + e - 1
-    int32_t deg[NPT], ent[NPT], oslot[NPT];
-    uint32_t oreaders[NPT]; // multi-GPU: the ranks that read this node's q (bit r), for the nodes with an interface slot
+    int32_t deg[NPT], ent[NPT];
+    // multi-GPU: a node other ranks read has an interface slot and a mask of reading ranks (bit r).  Both live in LDS, one
+    // word per node (slot | readers << 24; s_opk), flagged by bit 6 of the node's flags: as registers they were spilled, and
+    // their reload inside the node slot waited for the memory counter -- i.e. for the slot's own granule stores.
+    [[maybe_unused]] uint32_t *s_opk = (uint32_t *)(s_part + kPersistPartDoubles);
     // global (Hilbert) id of slot s's node: the workgroup's tiles are consecutive
     const int32_t node_base = __builtin_amdgcn_readfirstlane(((MG ? P.t0 : 0) + (int32_t)blockIdx.x * P.tiles_per_wg) * B);
     auto node_of = [&](int s) { return node_base + s * THREADS + tid; };
@@ -867,8 +918,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         const int l = t_loc(s), lt = t_lt(s);
         const int32_t t = (MG ? P.t0 : 0) + blockIdx.x * P.tiles_per_wg + l;
         double2 *xy = t_xy(s), *pim = xy + capx, *hr = pim + cap, *xs = hr + maxh;
-        oslot[s] = -1;
-        oreaders[s] = 0;
+        if (MG) s_opk[s * THREADS + tid] = 0xffffffffu;
         deg[s] = 0;
         ent[s] = 0;
         flags.set(s, 3);
@@ -992,11 +1042,14 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         }
         if ((flags[s] & 20) == 20) put_granules(P.qg + 4 * nd, tag0, make_double2(0.0, 0.0)); // q_{-1} = 0, parity 0
         if (MG && (flags[s] & 16)) {
-            oslot[s] = P.own_qslot[nd];
-            if (oslot[s] >= 0) {
-                if (!P.win_shared) oreaders[s] = P.iface_readers[oslot[s]];
-                asm volatile("" : "+v"(oreaders[s])); // landed: nothing of it is in flight when the stores begin
-                publish_q(P, 0, oslot[s], oreaders[s], tag0, make_double2(0.0, 0.0));
+            const int32_t osl = P.own_qslot[nd];
+            if (osl >= 0) {
+                uint32_t ord = 0;
+                if (!P.win_shared) ord = P.iface_readers[osl];
+                asm volatile("" : "+v"(ord)); // landed: nothing of it is in flight when the stores begin
+                s_opk[s * THREADS + tid] = (uint32_t)osl | (ord << 24); // (an inbox holds far fewer than 2^24 slots: the host checks)
+                flags.set(s, flags[s] | 64u);
+                publish_q(P, 0, osl, ord, tag0, make_double2(0.0, 0.0));
             }
         }
     }
@@ -1356,8 +1409,10 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
 #else
             if ((flags[s] & 20) == 20) put_granules(P.qg + 4 * ((int64_t)(par ^ 1) * P.N + node_of(s)), epoch + 1, qn);
 #endif
-            if (MG && oslot[s] >= 0)
-                publish_q(P, par ^ 1, oslot[s], oreaders[s], epoch + 1, qn);
+            if (MG && (flags[s] & 64u)) {
+                const uint32_t opk = s_opk[s * THREADS + tid];
+                publish_q(P, par ^ 1, (int32_t)(opk & 0xffffffu), opk >> 24, epoch + 1, qn);
+            }
             acc[0] = fma(r[s].y, r[s].y, fma(r[s].x, r[s].x, acc[0]));
             acc[1] = fma(pa.y, fy, fma(pa.x, fx, acc[1]));
             acc[2] = fma(r[s].y, fy, fma(r[s].x, fx, acc[2]));
@@ -1415,7 +1470,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
 #ifdef MAG_PERSIST_STAMPS
         unsigned long long *xs_ = stamp_sum + kStampPhases + 2; // (LDS as well: no stack object, no scratch in the diagnostic build)
         if (stamping) xs_[0] = xs_[1] = xs_[2] = xs_[3] = xs_[4] = 0;
-        if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec)
+        if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec, stamping ? xs_ : nullptr)
                : !persist_exchange<NH, EB>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk, s_part, Sx, stamping ? xs_ : nullptr))
             return;
         if (stamping) { // inside the exchange: wait before the first sweep / sweeps until complete / record reduction
@@ -1635,12 +1690,13 @@ int persist_tiles_per_wg(int32_t B, int threads)
 
 // dynamic LDS of a launch; every instantiation also carries 256 bytes of static LDS (the library's __syncthreads_and / _or),
 // which the host's fit test adds (kPersistStaticLds)
-size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh, int threads, int eb_mode, int32_t pool)
+size_t persist_lds_bytes(int32_t B, int32_t cap, int32_t maxh, int threads, int eb_mode, int32_t pool, bool mg)
 {
     const size_t tiles = (size_t)persist_tiles_per_wg(B, threads);
     const size_t capx = eb_mode == 2 ? (size_t)B : (size_t)cap; // with overflow blocks the first area holds q of the owned nodes only
     return tiles * (capx + (size_t)cap + (size_t)maxh + (size_t)B) * 16 + 2 * 256 * 16 +
-           (4 * ((size_t)threads / 64) + 4 + 4 * 32 + kPersistPartDoubles) * 8 + 16 + (eb_mode == 2 ? 32 * (size_t)pool : 0);
+           (4 * ((size_t)threads / 64) + 4 + 4 * 32 + kPersistPartDoubles) * 8 + 16 + (eb_mode == 2 ? 32 * (size_t)pool : 0) +
+           (mg ? 4 * (size_t)persist_npt(threads) * (size_t)threads : 0); // several ranks: the interface words (s_opk)
 }
 
 template <int THREADS>
@@ -1677,7 +1733,7 @@ static void persist_launch_t(const PersistParams &P, int32_t B, int32_t grid, si
 void persist_launch(const PersistParams &P, int32_t B, int32_t grid, int threads, int eb_mode, hipStream_t s)
 {
     if (!kPersistEdgeBlocks || (eb_mode == 2 && P.nranks > 1)) eb_mode = 0;
-    const size_t lds = persist_lds_bytes(B, P.cap, P.maxh, threads, eb_mode, P.pool_cap);
+    const size_t lds = persist_lds_bytes(B, P.cap, P.maxh, threads, eb_mode, P.pool_cap, P.nranks > 1);
 #ifdef MAG_PERSIST_768
     if (threads == 768) return persist_launch_t<768>(P, B, grid, lds, 0, s);
 #endif

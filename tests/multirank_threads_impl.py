@@ -147,16 +147,15 @@ def test_eight_ranks_on_chip_kernels_exchange_through_inboxes(case):
 
 
 def test_eight_ranks_on_chip_edge_blocks(case, monkeypatch):
-    """The multi-GPU instantiation of the on-chip kernel with edge blocks in registers (opt-in: MAG_TUNE_PERSIST_MG_BLOCKS;
-    the stacked plates are structured, so every rank finds the mesh eligible): same answers, and the stats say which
-    instantiation ran.  (Off by default until a multi-GPU node has measured it: it does not fit the registers without
-    reloading a sixth of the blocks from scratch memory every iteration.)"""
-    monkeypatch.setenv("MAG_TUNE_PERSIST_MG_BLOCKS", "1")
+    """The multi-GPU instantiation of the on-chip kernel with edge blocks in registers (the default across ranks since round
+    4; the stacked plates are structured, so every rank finds the mesh eligible): same answers, and the stats say which
+    instantiation ran; MAG_TUNE_PERSIST_MG_BLOCKS=0 keeps the triangle walk with cached weights."""
     results = run_ranks(case[0], inboxes=True, solves=2, cg_variant=2, tile_nodes=512)
     check(case, results, kernel=2, exchange=2)
     assert all(o["edge_blocks"] == 1 for outs in results for o in outs)
-    monkeypatch.delenv("MAG_TUNE_PERSIST_MG_BLOCKS")
+    monkeypatch.setenv("MAG_TUNE_PERSIST_MG_BLOCKS", "0")
     results = run_ranks(case[0], inboxes=True, cg_variant=2, tile_nodes=512)
+    check(case, results, kernel=2, exchange=2)
     assert all(o["edge_blocks"] == 0 and o["cg_kernel"] == 2 for outs in results for o in outs)
 
 
