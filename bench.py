@@ -199,6 +199,8 @@ def fixture_parity(workload, prob, u, f, stress, iterations, stop, tol):
     rel = lambda a, b: float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
     iu, ie = fx["dof_idx"], fx["elem_idx"]
     slack = 0 if "1 thread" in str(fx["solver"]) else max(2, int(fx["iterations"]) // 1000)
+    if workload == "frontal1m":  # the edge blocks add a node's triangles in another order than the oracle's rows: the count
+        slack = max(2, int(fx["iterations"]) // 100)  # wobbles at the threshold (plain CG's residual is not monotone)
     d = {"fixture": os.path.relpath(path, ROOT), "oracle_iterations": int(fx["iterations"]), "iterations": int(iterations),
          "mesh_is_the_fixtures": bool(mesh_ok), "stop_rule_is_the_fixtures": bool(rule_ok),
          "rel_l2_u_sampled": rel(u[iu], fx["u_at"]),
@@ -309,16 +311,29 @@ def unstructured_leg(device, tol, reps=3):
             c.run()
             ms.append(c.stats()["ms_total"])
         st = c.stats()
-        u = c.download()[0]
+        u, f_out, s_out = c.download()
         r = prob.f_in - c.apply_operator(u)  # f - K u on every DOF; the unknowns are where u is not prescribed
         free = prob.u_known == 0
         verify = float(np.linalg.norm(r[free]) / max(st["rhs_norm"], 1e-300))
+    # against the oracle's sampled solution at full size: one more solve at the FIXTURE's tolerance (1e-10: at a relative 1e-8
+    # the solution of this mesh is only determined to ~2e-8, tests/golden/make_fullsize_fixtures.py)
+    parity = None
+    fpath = os.path.join(ROOT, "tests", "golden", "fullsize_frontal1m.npz")
+    if os.path.exists(fpath):
+        ftol = float(np.load(fpath, allow_pickle=False)["rel_tol"])
+        with Context(device=device, stop_mode=_lib.MAG_STOP_REL, tol=ftol) as c:
+            c.upload_problem(prob)
+            c.run()
+            fst = c.stats()
+            fu, ff, fs = c.download()
+        parity = fixture_parity("frontal1m", prob, fu, ff, fs, int(fst["iterations"]), "rel", ftol)
+        parity["tol"] = ftol
     mean_ms = sum(ms) / len(ms)
     return {"workload": f"frontal1m: {desc}, {E} triangles, {N} nodes, left edge fixed, right edge ux=delta; CG stop=rel tol={tol:g}",
             "elements": E, "nodes": N, "steps": reps, "ms_per_step": mean_ms, "value": E / (mean_ms * 1e-3), "unit": "elements/s",
             "cg_kernel": int(st["cg_kernel"]), "edge_blocks": int(st["edge_blocks"]), "iterations": int(st["iterations"]),
             "us_per_iteration": st["ms_cg"] * 1e3 / max(int(st["iterations"]), 1), "converged": int(st["converged"]),
-            "verify_rel_residual": verify, "phases_ms": {k: st[k] for k in ("ms_order", "ms_csr_symbolic", "ms_assemble",
+            "verify_rel_residual": verify, "fixture_parity": parity, "phases_ms": {k: st[k] for k in ("ms_order", "ms_csr_symbolic", "ms_assemble",
                                                                            "ms_bc", "ms_cg", "ms_post", "ms_total")},
             "seconds": time.perf_counter() - t0}
 

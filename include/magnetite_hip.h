@@ -192,8 +192,10 @@ typedef struct mag_stats {
                                     `final_cost` is then the cost of the iterate actually returned                  */
     int32_t edge_blocks;    /* cg_kernel 2 only: 1 when the on-chip kernel ran its edge-block instantiation (every node's
                                triangles folded into at most six symmetric 2 x 2 blocks held in registers: meshes whose
-                               nodes all carry one fan of at most six triangles, closed, or five, open), 0 when it walked
-                               the triangles (any other mesh)                                                       */
+                               nodes all carry one fan of at most six triangles, closed, or five, open); 2 when it ran the
+                               edge-block instantiation WITH OVERFLOW (rows that are one fan of any length -- gmsh-type
+                               meshes: the blocks beyond six per node in an LDS pool; single GPU); 0 when it walked the
+                               triangles (nodes with several fans, or a pool that does not fit)                     */
     int32_t reserved0;
 } mag_stats;
 

@@ -275,6 +275,8 @@ def baseline_problem(which, scale=1.0):
     if which == "hole1m":
         n = grid_for_triangles(1e6 * scale * scale, np.pi * 0.15 ** 2)
         return config_fixed_left_pull_right(plate_with_holes(n))
+    if which == "frontal1m":  # round 4: the unstructured stand-in for a gmsh mesh (frontal_like), 1 006 602 triangles
+        return config_fixed_left_pull_right(frontal_like(max(4, int(660 * scale)), 0.4, 1))
     if which == "plate4m":
         return config_fixed_left_pull_right(plate(max(2, int(1414 * scale))))
     if which == "multihole16m":

@@ -26,6 +26,10 @@ from magnetite_amd import meshgen  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SEED, NSAMPLE, TOL = 20261004, 4096, 1e-8
+# frontal1m (round 4, the unstructured stand-in for a gmsh mesh): at a relative 1e-8 its solution is only determined to ~2e-8
+# (two correct solves that stop a few iterations apart differ by that much: the triangle walk and the edge blocks of the same
+# library do), so a 1e-8 parity bar needs a tighter stop -- its fixture is taken at 1e-10
+TOLS = {"frontal1m": 1e-10}
 
 
 def sample_indices(n, k=NSAMPLE, seed=SEED):
@@ -34,6 +38,7 @@ def sample_indices(n, k=NSAMPLE, seed=SEED):
 
 def main(names):
     for name in names:
+        TOL = TOLS.get(name, globals()["TOL"])
         p = meshgen.baseline_problem(name)
         N, E = p.mesh.num_nodes, p.mesh.num_elements
         t0 = time.time()

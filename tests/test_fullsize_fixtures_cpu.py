@@ -11,7 +11,7 @@ from magnetite_amd import meshgen
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("name", ["hole1m", "plate4m", "multihole16m"])
+@pytest.mark.parametrize("name", ["hole1m", "plate4m", "multihole16m", "frontal1m"])
 def test_fixture_is_complete_and_matches_its_mesh(name):
     fx = np.load(os.path.join(GOLDEN, f"fullsize_{name}.npz"), allow_pickle=False)
     for key in ("workload", "num_nodes", "num_elements", "rel_tol", "solver", "iterations", "final_cost", "u_norm",
@@ -19,7 +19,8 @@ def test_fixture_is_complete_and_matches_its_mesh(name):
                 "xy_checksum", "conn_checksum"):
         assert key in fx.files, key
     N, E = int(fx["num_nodes"]), int(fx["num_elements"])
-    assert str(fx["workload"]) == name and float(fx["rel_tol"]) == 1e-8 and int(fx["iterations"]) > 1000
+    # (frontal1m, the unstructured mesh, is taken at 1e-10: at 1e-8 its solution is only determined to ~2e-8)
+    assert str(fx["workload"]) == name and float(fx["rel_tol"]) == (1e-10 if name == "frontal1m" else 1e-8) and int(fx["iterations"]) > 1000
     assert fx["dof_idx"].shape == fx["u_at"].shape == fx["f_at"].shape == (4096,) and fx["dof_idx"].max() < 2 * N
     assert fx["elem_idx"].shape == fx["stress_at"].shape == (4096,) and fx["elem_idx"].max() < E
     assert np.all(np.diff(fx["dof_idx"]) > 0) and np.all(np.isfinite(fx["u_at"])) and np.all(np.isfinite(fx["stress_at"]))

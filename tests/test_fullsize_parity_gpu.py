@@ -35,7 +35,8 @@ def fixture(name):
     return np.load(path, allow_pickle=False)
 
 
-CASES = [("hole1m", 2), ("hole1m", 1), ("plate4m", 1), ("multihole16m", 1)]
+# (frontal1m, round 4: the unstructured stand-in for a gmsh mesh -- on chip with overflow edge blocks, and streamed)
+CASES = [("hole1m", 2), ("hole1m", 1), ("plate4m", 1), ("multihole16m", 1), ("frontal1m", 2), ("frontal1m", 1)]
 
 
 @pytest.mark.parametrize("name,variant", CASES)
@@ -52,6 +53,8 @@ def test_sampled_oracle_solution_at_baseline_size(built, name, variant):
     # same recurrences, same stop rule: the iteration counts agree (the serial oracle's to the iteration; the OpenMP
     # oracle used for 16M reduces its dot products in a different order)
     slack = 0 if "1 thread" in str(fx["solver"]) else max(2, int(fx["iterations"]) // 1000)
+    if name == "frontal1m":  # the kernels add a node's triangles in another order than the oracle's rows (edge blocks; ring
+        slack = max(2, int(fx["iterations"]) // 100)  # order): the count wobbles at the threshold (the residual is not monotone)
     assert abs(int(out["iterations"]) - int(fx["iterations"])) <= slack, (out["iterations"], int(fx["iterations"]))
     iu, ie = fx["dof_idx"], fx["elem_idx"]
     assert rel(out["u"][iu], fx["u_at"]) <= TOL_U
