@@ -248,9 +248,11 @@ def roofline_onchip(E, N, iters, ms_cg, pmc, tile, edge_blocks=False):
     tf = flops / (ms_cg * 1e-3) / 1e12
     d = {"kernel": "k_cg_persist<%d> (the whole CG solve in ONE launch: state resident in registers and LDS, grid-wide "
                    "exchange by tagged granules every iteration; %s)"
-                   % (tile, "edge-block instantiation: six symmetric 2 x 2 blocks per node in registers" if edge_blocks
-                      else "triangle-walk instantiation: cached triangle weights"),
-         "edge_blocks": bool(edge_blocks),
+                   % (tile, ("edge-block instantiation with overflow: six symmetric 2 x 2 blocks per node in registers, the blocks of "
+                             "longer rows in an LDS pool (unstructured meshes)") if int(edge_blocks) == 2
+                      else ("edge-block instantiation: six symmetric 2 x 2 blocks per node in registers" if edge_blocks
+                            else "triangle-walk instantiation: cached triangle weights")),
+         "edge_blocks": bool(edge_blocks), "edge_block_mode": int(edge_blocks),
          "bound": "valu-fp64", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
          "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "flops_per_launch": flops,
          "flops_formula": "(110E + 20N) x iterations (SURVEY 8d: ~110 flop per element-loop SpMV element + 10 flop per "
@@ -604,7 +606,7 @@ def main():
             tile_key = "none"
         if kind == 2:
             roofline = roofline_onchip(Eloc, Nloc, iters, st["ms_cg"], load_pmc(f"{tile_key}:kernel2"), args.tile,
-                                       bool(st.get("edge_blocks", 0)))
+                                       int(st.get("edge_blocks", 0)))
         elif kind == 4:  # fp32 leg: value terms halved (r, q, p, x in and out 64N, coordinates 8N, mask 1N); no timing
             # hook of its own, so the launch time is the CG phase / iterations (graph gaps and early exits included)
             roofline = kernel_line("k_cg_fused32<%d> (whole CG iteration in one launch, fp32 state)" % args.tile,
@@ -655,7 +657,7 @@ def main():
             # numeric assembly (K_e + CSR rows per element tile + BC elimination) against the HBM roof with SURVEY 8(d)'s
             # bytes (k_assemble_fan: fp64-issue-bound; MAG_TUNE_ASSEMBLY selects the older kernels); the
             # CSR pattern is ms_csr_symbolic
-            "assembly": ({"kernel": "k_assemble_fan + k_rhs_from_csr", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+            "assembly": ({"kernel": "k_assemble_fan + k_rhs_touched (b = 0.0 + f of the other rows comes from the ordering phase)", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                           "bytes": 12.0 * Eloc + 240.0 * Nloc, "bytes_formula": "12E+240N (SURVEY 8d), per-GPU share",
                           "ms": asm_ms, "achieved": (12.0 * Eloc + 240.0 * Nloc) / (asm_ms * 1e-3) / 1e9,
                           "frac": (12.0 * Eloc + 240.0 * Nloc) / (asm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}

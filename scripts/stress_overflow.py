@@ -1,0 +1,70 @@
+"""One-off randomized stress run of the on-chip kernel's overflow edge-block instantiation (edge_blocks == 2): random
+unstructured meshes -- jittered-lattice Delaunay at several jitters and sizes (valence 4-10), random-point Delaunay
+(valence 3-12+), with holes cut out (open fans of every length at the hole boundaries), shuffled numbering, clockwise
+elements, point loads and prescribed displacements -- against the oracle and against the triangle walk of the same
+library.   python scripts/stress_overflow.py [n]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ["MAG_TUNE_PERSIST_MIN_K"] = "1"
+import oracle  # noqa: E402
+from magnetite_amd import Context, meshgen  # noqa: E402
+from test_gpu_parity import _poisson_delaunay  # noqa: E402
+
+
+def cut_holes(mesh, rng, k):
+    """drop the triangles whose centroid lies in one of k random discs (and the nodes nothing uses any more)"""
+    c = mesh.xy[mesh.conn].mean(axis=1)
+    keep = np.ones(len(c), dtype=bool)
+    for _ in range(k):
+        x0, y0 = rng.uniform(0.2, 0.8, 2)
+        r = rng.uniform(0.04, 0.12)
+        keep &= (c[:, 0] - x0) ** 2 + (c[:, 1] - y0) ** 2 > r * r
+    conn = mesh.conn[keep]
+    used = np.zeros(mesh.num_nodes, dtype=bool)
+    used[conn.reshape(-1)] = True
+    remap = np.cumsum(used) - 1
+    return meshgen.Mesh(np.ascontiguousarray(mesh.xy[used]), remap[conn].astype(np.int32), mesh.name + f"_holes{k}")
+
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+worst, bad, modes = 0.0, [], {}
+t0 = time.time()
+for seed in range(900, 900 + n):
+    rng = np.random.default_rng(seed)
+    kind = seed % 4
+    if kind == 3:
+        mesh = _poisson_delaunay(int(rng.integers(3000, 16000)), seed)
+    else:
+        mesh = meshgen.frontal_like(int(rng.integers(50, 150)), float(rng.uniform(0.3, 0.5)), seed)
+    if seed % 3 == 0:
+        mesh = cut_holes(mesh, rng, int(rng.integers(1, 4)))
+    if seed % 5 == 0:
+        mesh = meshgen.clockwise(mesh)
+    mesh = meshgen.shuffle(mesh, seed)
+    p = (meshgen.config_fixed_left_point_load if seed % 2 else meshgen.config_fixed_left_pull_right)(mesh)
+    ref = oracle.run(p.xy_flat, p.conn_flat, p.u_known, p.u_in, p.f_in, p.youngs_modulus, p.poisson_ratio,
+                     p.part_thickness, path="sparse")
+    with Context(device=0, tile_nodes=512, assemble_csr=(1, 0)[seed % 2]) as c:
+        out = c.solve(p)
+        st = c.stats()
+        os.environ["MAG_TUNE_PERSIST_TRIANGLES"] = "1"
+        walk = c.solve(p)
+        del os.environ["MAG_TUNE_PERSIST_TRIANGLES"]
+    m = (st["cg_kernel"], st["edge_blocks"])
+    modes[m] = modes.get(m, 0) + 1
+    err = np.linalg.norm(out["u"] - ref["u"]) / np.linalg.norm(ref["u"])
+    errw = np.linalg.norm(out["u"] - walk["u"]) / np.linalg.norm(walk["u"])
+    worst = max(worst, err)
+    ok = out["converged"] == 1 and err <= 1e-8 and errw <= 1e-8 and abs(out["iterations"] - ref["iterations"]) <= max(5, ref["iterations"] // 20)
+    if not ok:
+        bad.append((seed, mesh.name, p.mesh.num_nodes, err, errw, out["iterations"], ref["iterations"], m))
+        print("MISS", bad[-1], flush=True)
+print(f"{n} problems in {time.time() - t0:.0f}s, (cg_kernel, edge_blocks) used {modes}, worst rel-L2 {worst:.3e}, failures: {bad}")
+sys.exit(1 if bad else 0)
