@@ -75,14 +75,17 @@ __device__ inline void corner_force(const double2 ca, const double2 pa, const do
 {
     const double ba = cb.y - cc.y, bb = cc.y - ca.y, bc = ca.y - cb.y;
     const double ga = cc.x - cb.x, gb = ca.x - cc.x, gc = cb.x - ca.x;
-    const double twoA = gc * bb - gb * bc;
-    const double ex = ba * pa.x + bb * pb.x + bc * pc.x;
-    const double ey = ga * pa.y + gb * pb.y + gc * pc.y;
-    const double g = ga * pa.x + ba * pa.y + gb * pb.x + bb * pb.y + gc * pc.x + bc * pc.y;
+    // (explicit FMAs: this file is compiled with -ffp-contract=off since round 4 -- the rounding of the matrix-free kernels is
+    // defined here, not by the compiler; the kernels that restate the reference's iteration to the letter, the two-launch
+    // variant and the CSR operator, keep their separate multiplications and additions: Rust never fuses)
+    const double twoA = fma(gc, bb, -(gb * bc));
+    const double ex = fma(bc, pc.x, fma(bb, pb.x, ba * pa.x));
+    const double ey = fma(gc, pc.y, fma(gb, pb.y, ga * pa.y));
+    const double g = fma(bc, pc.y, fma(gc, pc.x, fma(bb, pb.y, fma(gb, pb.x, fma(ba, pa.y, ga * pa.x)))));
     const double w = c0 * fast_rcp(twoA);
-    const double sx = ex + nu * ey, sy = nu * ex + ey, tq = h * g;
-    fx += w * (ba * sx + ga * tq);
-    fy += w * (ga * sy + ba * tq);
+    const double sx = fma(nu, ey, ex), sy = fma(nu, ex, ey), tq = h * g;
+    fx = fma(w, fma(ba, sx, ga * tq), fx);
+    fy = fma(w, fma(ga, sy, ba * tq), fy);
 }
 
 // State machine of the two-launch iteration (operator launch): judge iterate k from its exact r.r, record the verdict,
@@ -866,7 +869,7 @@ __device__ inline bool fused_step(FusedState *st, int par, long long j, double t
     if (finished || broke || maxed) return false;
     const double rho = NS == 5 ? S[2] : rr;
     alpha = rho / S[1];
-    beta = (rho + 2.0 * alpha * S[NS - 2] + alpha * alpha * S[NS - 1]) / rho;
+    beta = fma(alpha * alpha, S[NS - 1], fma(2.0 * alpha, S[NS - 2], rho)) / rho;
     return true;
 }
 
@@ -903,8 +906,8 @@ __device__ inline void block_sum4(double (&v)[4], double *s_red)
 __device__ inline double2 apply_minv(const float4 mi, const double2 r)
 {
     double2 z;
-    z.x = (double)mi.x * r.x + (double)mi.y * r.y;
-    z.y = (double)mi.y * r.x + (double)mi.z * r.y;
+    z.x = fma((double)mi.y, r.y, (double)mi.x * r.x);
+    z.y = fma((double)mi.z, r.y, (double)mi.y * r.x);
     return z;
 }
 
@@ -999,23 +1002,23 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
     for (;;) {
         // r_j, x_j, p_j of the owned node
         double2 rn, pn;
-        rn.x = ar.x + alpha * aq.x;
-        rn.y = ar.y + alpha * aq.y;
+        rn.x = fma(alpha, aq.x, ar.x);
+        rn.y = fma(alpha, aq.y, ar.y);
         const double2 zn = PRE ? apply_minv(mi, rn) : rn;
-        pn.x = -zn.x + beta * ap.x;
-        pn.y = -zn.y + beta * ap.y;
-        xo.x += alpha * ap.x;
-        xo.y += alpha * ap.y;
+        pn.x = fma(beta, ap.x, -zn.x);
+        pn.y = fma(beta, ap.y, -zn.y);
+        xo.x = fma(alpha, ap.x, xo.x);
+        xo.y = fma(alpha, ap.y, xo.y);
         __syncthreads(); // previous tile's readers are done with the LDS images
         s_xy[tid] = ca;
         s_p[tid] = pn;
         if (hvalid) {
             double2 hrn, hpn;
-            hrn.x = hr.x + alpha * hq.x;
-            hrn.y = hr.y + alpha * hq.y;
+            hrn.x = fma(alpha, hq.x, hr.x);
+            hrn.y = fma(alpha, hq.y, hr.y);
             const double2 hzn = PRE ? apply_minv(hmi, hrn) : hrn;
-            hpn.x = -hzn.x + beta * hp.x;
-            hpn.y = -hzn.y + beta * hp.y;
+            hpn.x = fma(beta, hp.x, -hzn.x);
+            hpn.y = fma(beta, hp.y, -hzn.y);
             s_xy[B + tid] = hc;
             s_p[B + tid] = hpn;
         }
@@ -1028,11 +1031,11 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
                 if (hs >= 0) hq2 = P.comm_in_q[hs];
             }
             double2 hrn, hpn;
-            hrn.x = rec.r.x + alpha * hq2.x;
-            hrn.y = rec.r.y + alpha * hq2.y;
+            hrn.x = fma(alpha, hq2.x, rec.r.x);
+            hrn.y = fma(alpha, hq2.y, rec.r.y);
             const double2 hzn = PRE ? apply_minv(P.halo_minv[hoff + hh], hrn) : hrn;
-            hpn.x = -hzn.x + beta * rec.p.x;
-            hpn.y = -hzn.y + beta * rec.p.y;
+            hpn.x = fma(beta, rec.p.x, -hzn.x);
+            hpn.y = fma(beta, rec.p.y, -hzn.y);
             s_xy[B + hh] = P.halo_xy[hoff + hh];
             s_p[B + hh] = hpn;
         }
@@ -1057,16 +1060,16 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
             store2<WT>((double2 *)P.out, 3 * P.N, 3 * node + 2, pn);
             store2<WT>(P.x, P.N, node, xo);
             if (COMM && oslot >= 0) P.comm_out_q[oslot] = make_double2(fx, fy);
-            acc[0] += rn.x * rn.x + rn.y * rn.y;
-            acc[1] += pn.x * fx + pn.y * fy;
+            acc[0] = fma(rn.y, rn.y, fma(rn.x, rn.x, acc[0]));
+            acc[1] = fma(pn.y, fy, fma(pn.x, fx, acc[1]));
             if (PRE) {
                 const double2 zq = apply_minv(mi, make_double2(fx, fy));
-                acc[2] += rn.x * zn.x + rn.y * zn.y;
-                acc[NS - 2] += fx * zn.x + fy * zn.y;
-                acc[NS - 1] += fx * zq.x + fy * zq.y;
+                acc[2] = fma(rn.y, zn.y, fma(rn.x, zn.x, acc[2]));
+                acc[NS - 2] = fma(fy, zn.y, fma(fx, zn.x, acc[NS - 2]));
+                acc[NS - 1] = fma(fy, zq.y, fma(fx, zq.x, acc[NS - 1]));
             } else {
-                acc[2] += rn.x * fx + rn.y * fy;
-                acc[3] += fx * fx + fy * fy;
+                acc[2] = fma(rn.y, fy, fma(rn.x, fx, acc[2]));
+                acc[3] = fma(fy, fy, fma(fx, fx, acc[3]));
             }
         }
         t += gridDim.x;
@@ -1082,11 +1085,11 @@ __global__ void __launch_bounds__(B) k_cg_fused(const FusedParams P)
                 const Rqp rec = P.in[g];
                 const double2 qg = P.comm_in_q[k];
                 double2 rn, pn;
-                rn.x = rec.r.x + alpha * qg.x;
-                rn.y = rec.r.y + alpha * qg.y;
+                rn.x = fma(alpha, qg.x, rec.r.x);
+                rn.y = fma(alpha, qg.y, rec.r.y);
                 const double2 zg = PRE ? apply_minv(P.minvP[g], rn) : rn;
-                pn.x = -zg.x + beta * rec.p.x;
-                pn.y = -zg.y + beta * rec.p.y;
+                pn.x = fma(beta, rec.p.x, -zg.x);
+                pn.y = fma(beta, rec.p.y, -zg.y);
                 P.out[g].r = rn;
                 P.out[g].p = pn;
                 P.comm_out_q[k] = make_double2(0.0, 0.0);
@@ -1216,22 +1219,22 @@ __global__ void __launch_bounds__(B, 4) k_cg_fused_dma(const FusedParams P)
         const double2 ca = s_xy[tid];
         // r_j, x_j, p_j of the owned node
         double2 rn, pn;
-        rn.x = ar.x + alpha * aq.x;
-        rn.y = ar.y + alpha * aq.y;
+        rn.x = fma(alpha, aq.x, ar.x);
+        rn.y = fma(alpha, aq.y, ar.y);
         const double2 zn = PRE ? apply_minv(mi, rn) : rn;
-        pn.x = -zn.x + beta * ap.x;
-        pn.y = -zn.y + beta * ap.y;
-        xo.x += alpha * ap.x;
-        xo.y += alpha * ap.y;
+        pn.x = fma(beta, ap.x, -zn.x);
+        pn.y = fma(beta, ap.y, -zn.y);
+        xo.x = fma(alpha, ap.x, xo.x);
+        xo.y = fma(alpha, ap.y, xo.y);
         s_p[tid] = pn;
         if (hvalid) {
             const double2 hr = s_hr[tid], hq = s_hq[tid], hp = s_hp[tid];
             double2 hrn, hpn;
-            hrn.x = hr.x + alpha * hq.x;
-            hrn.y = hr.y + alpha * hq.y;
+            hrn.x = fma(alpha, hq.x, hr.x);
+            hrn.y = fma(alpha, hq.y, hr.y);
             const double2 hzn = PRE ? apply_minv(hmi, hrn) : hrn;
-            hpn.x = -hzn.x + beta * hp.x;
-            hpn.y = -hzn.y + beta * hp.y;
+            hpn.x = fma(beta, hp.x, -hzn.x);
+            hpn.y = fma(beta, hp.y, -hzn.y);
             s_p[B + tid] = hpn;
         }
         for (int32_t hh = tid + B; hh < nh; hh += B) { // more halo nodes than threads (rare)
@@ -1243,11 +1246,11 @@ __global__ void __launch_bounds__(B, 4) k_cg_fused_dma(const FusedParams P)
                 if (hs >= 0) hq2 = P.comm_in_q[hs];
             }
             double2 hrn, hpn;
-            hrn.x = rec.r.x + alpha * hq2.x;
-            hrn.y = rec.r.y + alpha * hq2.y;
+            hrn.x = fma(alpha, hq2.x, rec.r.x);
+            hrn.y = fma(alpha, hq2.y, rec.r.y);
             const double2 hzn = PRE ? apply_minv(P.halo_minv[hoff + hh], hrn) : hrn;
-            hpn.x = -hzn.x + beta * rec.p.x;
-            hpn.y = -hzn.y + beta * rec.p.y;
+            hpn.x = fma(beta, rec.p.x, -hzn.x);
+            hpn.y = fma(beta, rec.p.y, -hzn.y);
             s_xy[B + hh] = P.halo_xy[hoff + hh];
             s_p[B + hh] = hpn;
         }
@@ -1279,16 +1282,16 @@ __global__ void __launch_bounds__(B, 4) k_cg_fused_dma(const FusedParams P)
         if (valid) {
             store2<WT>(P.x, P.N, node, xo);
             if (COMM && oslot >= 0) P.comm_out_q[oslot] = make_double2(fx, fy);
-            acc[0] += rn.x * rn.x + rn.y * rn.y;
-            acc[1] += pn.x * fx + pn.y * fy;
+            acc[0] = fma(rn.y, rn.y, fma(rn.x, rn.x, acc[0]));
+            acc[1] = fma(pn.y, fy, fma(pn.x, fx, acc[1]));
             if (PRE) {
                 const double2 zq = apply_minv(mi, make_double2(fx, fy));
-                acc[2] += rn.x * zn.x + rn.y * zn.y;
-                acc[NS - 2] += fx * zn.x + fy * zn.y;
-                acc[NS - 1] += fx * zq.x + fy * zq.y;
+                acc[2] = fma(rn.y, zn.y, fma(rn.x, zn.x, acc[2]));
+                acc[NS - 2] = fma(fy, zn.y, fma(fx, zn.x, acc[NS - 2]));
+                acc[NS - 1] = fma(fy, zq.y, fma(fx, zq.x, acc[NS - 1]));
             } else {
-                acc[2] += rn.x * fx + rn.y * fy;
-                acc[3] += fx * fx + fy * fy;
+                acc[2] = fma(rn.y, fy, fma(rn.x, fx, acc[2]));
+                acc[3] = fma(fy, fy, fma(fx, fx, acc[3]));
             }
         }
         t += gridDim.x;
@@ -1305,11 +1308,11 @@ __global__ void __launch_bounds__(B, 4) k_cg_fused_dma(const FusedParams P)
                 const Rqp rec = P.in[g];
                 const double2 qg = P.comm_in_q[k];
                 double2 rn, pn;
-                rn.x = rec.r.x + alpha * qg.x;
-                rn.y = rec.r.y + alpha * qg.y;
+                rn.x = fma(alpha, qg.x, rec.r.x);
+                rn.y = fma(alpha, qg.y, rec.r.y);
                 const double2 zg = PRE ? apply_minv(P.minvP[g], rn) : rn;
-                pn.x = -zg.x + beta * rec.p.x;
-                pn.y = -zg.y + beta * rec.p.y;
+                pn.x = fma(beta, rec.p.x, -zg.x);
+                pn.y = fma(beta, rec.p.y, -zg.y);
                 P.out[g].r = rn;
                 P.out[g].p = pn;
                 P.comm_out_q[k] = make_double2(0.0, 0.0);
@@ -1440,10 +1443,10 @@ __global__ void __launch_bounds__(B) k_fused_init(const double2 *bP, const float
             in[node] = rec;
             out[node] = rec;
             if (t >= t0 && t < t1) {
-                acc += b.x * b.x + b.y * b.y;
+                acc = fma(b.y, b.y, fma(b.x, b.x, acc));
                 if (minvP) {
                     const double2 zb = apply_minv(minvP[node], b);
-                    rho += b.x * zb.x + b.y * zb.y;
+                    rho = fma(b.y, zb.y, fma(b.x, zb.x, rho));
                 }
             }
         }
@@ -1651,12 +1654,12 @@ __global__ void __launch_bounds__(B) k_cg_fused32(const Fused32Params P)
     int32_t t = t_first + blockIdx.x;
     for (;;) {
         float2 rn, pn;
-        rn.x = ar.x + alpha * aq.x;
-        rn.y = ar.y + alpha * aq.y;
-        pn.x = -rn.x + beta * ap.x;
-        pn.y = -rn.y + beta * ap.y;
-        xo.x += alpha * ap.x;
-        xo.y += alpha * ap.y;
+        rn.x = fma(alpha, aq.x, ar.x);
+        rn.y = fma(alpha, aq.y, ar.y);
+        pn.x = fma(beta, ap.x, -rn.x);
+        pn.y = fma(beta, ap.y, -rn.y);
+        xo.x = fma(alpha, ap.x, xo.x);
+        xo.y = fma(alpha, ap.y, xo.y);
         __syncthreads();
         s_xy[tid] = ca;
         s_p[tid] = pn;
@@ -1675,10 +1678,10 @@ __global__ void __launch_bounds__(B) k_cg_fused32(const Fused32Params P)
                 }
             }
             float2 hrn, hpn;
-            hrn.x = r2.x + alpha * q2.x;
-            hrn.y = r2.y + alpha * q2.y;
-            hpn.x = -hrn.x + beta * p2.x;
-            hpn.y = -hrn.y + beta * p2.y;
+            hrn.x = fma(alpha, q2.x, r2.x);
+            hrn.y = fma(alpha, q2.y, r2.y);
+            hpn.x = fma(beta, p2.x, -hrn.x);
+            hpn.y = fma(beta, p2.y, -hrn.y);
             s_xy[B + hh] = c2;
             s_p[B + hh] = hpn;
         }
@@ -1704,10 +1707,10 @@ __global__ void __launch_bounds__(B) k_cg_fused32(const Fused32Params P)
             P.out[node] = o;
             P.x[node] = xo;
             if (COMM && oslot >= 0) P.comm_out_q[oslot] = make_double2((double)fx, (double)fy);
-            acc[0] += (double)rn.x * rn.x + (double)rn.y * rn.y;
-            acc[1] += (double)pn.x * fx + (double)pn.y * fy;
-            acc[2] += (double)rn.x * fx + (double)rn.y * fy;
-            acc[3] += (double)fx * fx + (double)fy * fy;
+            acc[0] = fma((double)rn.y, (double)rn.y, fma((double)rn.x, (double)rn.x, acc[0]));
+            acc[1] = fma((double)pn.y, (double)fy, fma((double)pn.x, (double)fx, acc[1]));
+            acc[2] = fma((double)rn.y, (double)fy, fma((double)rn.x, (double)fx, acc[2]));
+            acc[3] = fma((double)fy, (double)fy, fma((double)fx, (double)fx, acc[3]));
         }
         t += gridDim.x;
         if (t >= t_end) break;
@@ -1722,10 +1725,10 @@ __global__ void __launch_bounds__(B) k_cg_fused32(const Fused32Params P)
                 const Rqp32 rec = P.in[g];
                 const float2 qg = iface_q(k);
                 float2 rn, pn;
-                rn.x = rec.r.x + alpha * qg.x;
-                rn.y = rec.r.y + alpha * qg.y;
-                pn.x = -rn.x + beta * rec.p.x;
-                pn.y = -rn.y + beta * rec.p.y;
+                rn.x = fma(alpha, qg.x, rec.r.x);
+                rn.y = fma(alpha, qg.y, rec.r.y);
+                pn.x = fma(beta, rec.p.x, -rn.x);
+                pn.y = fma(beta, rec.p.y, -rn.y);
                 P.out[g].r = rn;
                 P.out[g].p = pn;
                 P.comm_out_q[k] = make_double2(0.0, 0.0);
@@ -1819,7 +1822,7 @@ __global__ void __launch_bounds__(B) k_fused32_init(const double2 *bP, Rqp32 *in
             in[node] = rec;
             out[node] = rec;
             x[node] = z;
-            if (t >= t0 && t < t1) acc += (double)rec.r.x * rec.r.x + (double)rec.r.y * rec.r.y; // this rank's tiles
+            if (t >= t0 && t < t1) acc = fma((double)rec.r.y, (double)rec.r.y, fma((double)rec.r.x, (double)rec.r.x, acc)); // this rank's tiles
         }
     }
     const double tot = block_sum<B>(acc, s_red);
