@@ -98,3 +98,77 @@ def test_closing_triangle_folds_onto_entry_zero():
         two_a = pts[k - 1][0] * pts[k][1] - pts[k][0] * pts[k - 1][1]
         walk += fan_force_w(pts[k - 1], us[k - 1], pts[k], us[k], C0 / two_a)
     assert np.allclose(f6, walk, rtol=1e-11, atol=1e-11 * np.abs(walk).max())
+
+
+def overflow_layout(pts, nb=6):
+    """k_edge_blocks_ovf's placement (round 4): a row of n ring entries is streamed one triangle at a time -- block j is
+    K_ac of triangle j + K_ab of triangle j + 1 --; a CLOSED fan folds its closing triangle into blocks n - 2 and 0 (n - 1
+    blocks); blocks below nb stay in registers, the rest become pool records (block, ring entry); an OPEN fan of more than nb
+    entries keeps its LAST block in register position nb - 1 and its middle blocks nb - 1 .. n - 2 in the pool, so that u_first
+    and u_last are register entries.  Returns (register blocks with their entries, pool records with their entries, closed)."""
+    n = len(pts)
+    closed = n >= 3 and np.allclose(pts[-1], pts[0])
+    kb, _ = blocks_of(pts)
+    if closed:  # the closing triangle's K_ac lands in block n - 1 of blocks_of: fold it onto entry 0
+        kb = kb.copy()
+        kb[0] += kb[n - 1]
+        nblk = n - 1
+    else:
+        nblk = n
+    regs, pool = [(np.zeros(3), 0)] * nb, []
+    regs = list(regs)
+    open_long = not closed and n > nb
+    for j in range(nblk):
+        dest = j
+        if open_long and j >= nb - 1:
+            dest = nb - 1 if j == n - 1 else j + 1
+        if dest < nb:
+            regs[dest] = (kb[j], j)
+        else:
+            pool.append((dest - nb, kb[j], j))
+    pool = [(b, e) for _, b, e in sorted(pool, key=lambda t: t[0])]
+    return regs, pool, closed
+
+
+@pytest.mark.parametrize("closed", [True, False])
+@pytest.mark.parametrize("triangles", [2, 5, 6, 7, 8, 9, 12])
+def test_overflow_layout_reproduces_the_triangle_walk(closed, triangles):
+    """Rows of ANY length through six register blocks + pool records (ring_walk_blocks_ovf): the register blocks, the
+    telescoped antisymmetric part from register entries 0 and 5 only, then the pool records in order -- equal to the triangle
+    walk for closed fans of valence 3-12 and open fans of up to 12 triangles."""
+    if closed and triangles < 3:
+        pytest.skip("a closed fan has at least three triangles")
+    rng = np.random.default_rng(1000 * triangles + closed)
+    for _ in range(10):
+        pts = random_fan(rng, triangles, closed)
+        us = [rng.normal(size=2) for _ in pts]
+        if closed:
+            us[-1] = us[0]
+        walk = np.zeros(2)
+        for k in range(1, len(pts)):
+            two_a = pts[k - 1][0] * pts[k][1] - pts[k][0] * pts[k - 1][1]
+            walk += fan_force_w(pts[k - 1], us[k - 1], pts[k], us[k], C0 / two_a)
+        regs, pool, is_closed = overflow_layout(pts)
+        assert is_closed == closed
+        n = len(pts)
+        nblk = n - 1 if closed else n
+        assert len(pool) == max(0, nblk - 6)
+        # register entries: blocks the row does not have are zero blocks on a repeated entry (the last one)
+        ent = [e for _, e in regs]
+        for j in range(6):
+            if j >= min(nblk, 6) and not (not closed and n > 6):
+                ent[j] = min(n - 1, nblk - 1) if nblk > 0 else 0
+        f = np.zeros(2)
+        for (b, _), e in zip(regs, ent):
+            u = us[e]
+            f += [b[0] * u[0] + b[1] * u[1], b[1] * u[0] + b[2] * u[1]]
+        if not closed:  # kappa J (u_last - u_first), both from the registers: entry 0 and register entry 5
+            a = us[ent[5]] - us[ent[0]]
+            assert ent[5] == n - 1 or n <= 6
+            if n <= 6:
+                a = us[n - 1] - us[0]
+            f += [KAPPA * a[1], -KAPPA * a[0]]
+        for b, e in pool:
+            u = us[e]
+            f += [b[0] * u[0] + b[1] * u[1], b[1] * u[0] + b[2] * u[1]]
+        assert np.allclose(f, walk, rtol=1e-10, atol=1e-10 * np.abs(walk).max())

@@ -101,3 +101,27 @@ def test_polygon_mesher_is_deterministic_and_valid():
     assert np.all(areas(a) > 0)
     poly_area = 0.5 * abs(np.dot(outline[:, 0], np.roll(outline[:, 1], -1)) - np.dot(outline[:, 1], np.roll(outline[:, 0], -1)))
     assert areas(a).sum() == pytest.approx(poly_area, rel=1e-9)
+
+
+def test_frontal_like_mesh_is_deterministic_valid_and_has_gmsh_like_valences():
+    """meshgen.frontal_like, the stand-in for what gmsh's frontal mesher hands solver::run (mesher.rs:501-506; round 4):
+    deterministic for (n, jitter, seed), conforming and CCW, every node used, and at jitter 0.4 a valence histogram with about a
+    quarter of the nodes at five, half at six, a quarter at seven or more -- the rows the on-chip kernel's overflow edge blocks
+    exist for.  Its oracle solution is a valid CST solve (patch-like pull: ux grows along x)."""
+    a, b = meshgen.frontal_like(60, 0.4, 7), meshgen.frontal_like(60, 0.4, 7)
+    assert np.array_equal(a.xy, b.xy) and np.array_equal(a.conn, b.conn)
+    assert not np.array_equal(a.xy, meshgen.frontal_like(60, 0.4, 8).xy)
+    tri = a.xy[a.conn]
+    area = 0.5 * ((tri[:, 1, 0] - tri[:, 0, 0]) * (tri[:, 2, 1] - tri[:, 0, 1]) -
+                  (tri[:, 2, 0] - tri[:, 0, 0]) * (tri[:, 1, 1] - tri[:, 0, 1]))
+    assert np.all(area > 0) and abs(area.sum() - 1.0) < 1e-12  # CCW, and the triangles tile the unit square
+    assert np.array_equal(np.unique(a.conn), np.arange(a.num_nodes))
+    # conforming: every interior edge is shared by exactly two triangles, boundary edges by one
+    e = np.sort(np.concatenate([a.conn[:, [0, 1]], a.conn[:, [1, 2]], a.conn[:, [2, 0]]]), axis=1)
+    _, cnt = np.unique(e, axis=0, return_counts=True)
+    assert set(cnt.tolist()) <= {1, 2}
+    val = np.bincount(a.conn.reshape(-1), minlength=a.num_nodes)
+    frac = np.bincount(val, minlength=12) / a.num_nodes
+    assert 0.15 < frac[5] < 0.32 and 0.40 < frac[6] < 0.60 and 0.18 < frac[7:].sum() < 0.32 and val.max() <= 12
+    p = meshgen.baseline_problem("frontal1m", scale=0.05)
+    assert p.mesh.num_elements > 2000 and int((p.u_known == 1).sum()) > 50
