@@ -258,8 +258,13 @@ int ensure_order(mag_ctx *ctx)
                                    getenv("MAG_TUNE_FORCE_DIST") == nullptr && ctx->opt.precision == 0 &&
                                    ctx->opt.preconditioner == 0 && ctx->opt.cg_operator == MAG_OP_MATRIX_FREE &&
                                    ctx->opt.op_variant != 1 && !ctx->persist_failed;
+    // (round 4: on ONE GPU the on-chip kernel takes every mesh it can hold, the small ones included -- the reference's own
+    // examples are a few thousand triangles: 3.85 against 6.5 us per iteration for the streaming kernels replayed from a graph
+    // at 1k-27k triangles, and no graph to instantiate in the first solve (scripts/small_mesh_probe.py); across ranks the lower
+    // bound stays, so that every rank gets tiles)
     if (ctx->opt.tile_nodes == 0)
-        ctx->B = (N >= 512 * 512 || (on_chip_candidate && N >= 32768 && N <= (int64_t)ctx->comm.nranks * 1024 * 512))
+        ctx->B = (N >= 512 * 512 || (on_chip_candidate && (N >= 32768 || ctx->comm.nranks == 1) &&
+                                     N <= (int64_t)ctx->comm.nranks * 1024 * 512))
                      ? 512 : 256;
     const int32_t B = ctx->B;
     const int32_t T = (int32_t)((N + B - 1) / B);

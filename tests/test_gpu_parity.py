@@ -981,20 +981,41 @@ def test_on_chip_sibling_tiles_on_irregular_meshes(built, case):
 
 
 def test_one_context_alternates_between_streaming_and_on_chip_solves(built):
-    """The same context solves a mesh the library streams (auto tile 256), one it keeps on chip (auto tile 512), and the
-    first again: tile size, tables, graph and kernel choice all follow the problem, results equal fresh contexts'."""
-    small = meshgen.config_fixed_left_pull_right(meshgen.plate_with_holes(150))      # 22k nodes: streamed
+    """The same context solves a mesh the chip cannot hold (more than 524 288 nodes: streamed, one fused launch per iteration
+    replayed from a graph), one it keeps on chip, a small one (on chip as well since round 4: every mesh one GPU can hold), and
+    the first again: tile tables, graph and kernel choice all follow the problem, results equal fresh contexts'."""
+    big = meshgen.config_fixed_left_pull_right(meshgen.plate_with_holes(760))        # 577k nodes: streamed
     mid = meshgen.config_fixed_left_pull_right(meshgen.plate_with_holes(300))        # 90k nodes: on chip
+    small = meshgen.config_fixed_left_pull_right(meshgen.plate_with_holes(60))       # 3.6k nodes: on chip
+    assert big.mesh.num_nodes > 524288
+    kw = dict(stop_mode=MAG_STOP_REL, tol=1e-8)
     fresh = {}
-    for name, p in (("small", small), ("mid", mid)):
-        with Context(device=0) as c:
+    for name, p in (("big", big), ("mid", mid), ("small", small)):
+        with Context(device=0, **kw) as c:
             fresh[name] = (c.solve(p), c.stats()["cg_kernel"])
-    assert fresh["small"][1] == 1 and fresh["mid"][1] == 2
-    with Context(device=0) as c:
-        for name, p in (("small", small), ("mid", mid), ("small", small), ("mid", mid)):
+    assert fresh["big"][1] == 1 and fresh["mid"][1] == 2 and fresh["small"][1] == 2
+    with Context(device=0, **kw) as c:
+        for name, p in (("big", big), ("mid", mid), ("small", small), ("big", big), ("mid", mid)):
             out = c.solve(p)
             assert c.stats()["cg_kernel"] == fresh[name][1]
             assert np.array_equal(out["u"], fresh[name][0]["u"]) and out["iterations"] == fresh[name][0]["iterations"]
+
+
+def test_small_meshes_run_the_on_chip_kernel_by_default(built):
+    """Round 4: on one GPU the on-chip kernel takes every mesh it can hold -- the reference's own examples are a few thousand
+    triangles (3.85 against 6.5 us per iteration for the streamed kernels at 1k-27k triangles, and no graph to instantiate in
+    the first solve).  One tile and a half, a handful of tiles, the tensile fixture: oracle parity with the default options."""
+    for p in (meshgen.config_fixed_left_pull_right(meshgen.plate_with_holes(24)),
+              meshgen.config_fixed_left_point_load(meshgen.shuffle(meshgen.plate(48), 2)),
+              meshgen.config_fixed_left_pull_right(meshgen.frontal_like(30, 0.4, 5))):
+        ref = oracle_run(p)
+        with Context(device=0) as c:
+            out = c.solve(p)
+            st = c.stats()
+        assert st["cg_kernel"] == 2 and st["edge_blocks"] in (1, 2), p.mesh.name
+        assert out["converged"] == 1 and abs(out["iterations"] - ref["iterations"]) <= max(3, ref["iterations"] // 50)
+        for key in ("u", "f", "stress"):
+            assert rel(out[key], ref[key]) <= TOL_U, (p.mesh.name, key)
 
 
 def _disc(m, rings):
