@@ -499,6 +499,10 @@ int ensure_order(mag_ctx *ctx)
         const int kmax = magk::persist_tiles_per_wg(B, pthreads);
         const int32_t tiles_max = (T + R - 1) / R; // the most tiles any rank runs
         int k = cus > 0 ? (tiles_max + cus - 1) / cus : 0;
+        // a mesh of at most kmax tiles on one GPU (up to 2048 nodes: the size of the reference's own examples) goes to ONE
+        // workgroup: every tile is a sibling of every other, nothing is exchanged through memory (persist_single_workgroup)
+        const char *sw = getenv("MAG_TUNE_PERSIST_SINGLE_WG");
+        if (!mg && tiles_max <= kmax && !(sw && atoi(sw) == 0)) k = std::max(k, (int)tiles_max);
         // rehearsals: several ranks share ONE GPU and must all be co-resident -- fewer, fuller workgroups per rank
         if (const char *e = getenv("MAG_TUNE_PERSIST_K")) k = std::max(k, atoi(e));
         // Measured against the streaming kernel on the same 512-node tiles the on-chip kernel wins from one tile per

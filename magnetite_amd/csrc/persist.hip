@@ -857,10 +857,28 @@ __device__ inline double uniform_f64(double v)
                             __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
+// ONE workgroup holds the whole mesh (up to four tiles: the size of the reference's own examples): its own four sums are the
+// grid's, nothing is read through memory (no tile of another workgroup exists: no halo entry is live), and the exchange -- a
+// store-to-load round trip through the memory side, ~1.7 us of an iteration's ~3.9 at this size -- shrinks to one barrier.
+// s_S: the workgroup's sums, left there by thread 0 where the record is published (they are not kept in registers up to here: the
+// edge-block kernel has none to spare).
+template <int NH>
+__device__ inline void persist_single_workgroup(double *s_S, double (&Sx)[4], double2 (&hq)[NH])
+{
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Sx[c] = uniform_f64(s_S[c]);
+#pragma unroll
+    for (int e = 0; e < NH; ++e) hq[e] = make_double2(0.0, 0.0);
+    __syncthreads(); // (s_S is rewritten by the next iteration's sums)
+}
+
 // EBM: 0 the triangle walk, 1 edge blocks in registers (every row of the mesh a fan of at most six blocks: structured meshes),
 // 2 edge blocks with OVERFLOW (round 4: rows that are one fan of any length -- what gmsh's frontal meshes look like, a quarter
 // of their nodes with seven neighbours: blocks beyond the six in registers sit in an LDS pool of 32-byte records).
-template <int B, bool MG, int THREADS, int EBM>
+// ONE: the single-workgroup instantiation (the mesh is at most four tiles: persist_single_workgroup).  An instantiation of its
+// own, not a branch: the edge-block kernel sits at 256 of 256 registers, and a conditional exchange made the allocator spill 24.
+template <int B, bool MG, int THREADS, int EBM, bool ONE = false>
 __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
 {
     constexpr int kPersistThreads = THREADS;
@@ -1156,13 +1174,17 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
     persist_block_sum<THREADS>(acc, s_red, s_part);
     int par = 0;
     unsigned epoch = tag0; // the tags of successive exchanges
+    constexpr bool single_wg = ONE && !MG; // the whole mesh in this workgroup: no exchange at all
     if (tid < 2) // the block sums are in every thread: two threads publish the record's two pieces
         put_granules(P.recg + 4 * (2 * ((int64_t)par * cgrid + blockIdx.x) + tid), epoch,
                      tid == 0 ? make_double2(acc[0], acc[1]) : make_double2(acc[2], acc[3]));
+    if (single_wg && tid < 2) ((double2 *)s_S)[tid] = tid == 0 ? make_double2(acc[0], acc[1]) : make_double2(acc[2], acc[3]);
     double2 hq[NH]; // q of this thread's halo nodes
     double Sx[4] = {0.0, 0.0, 0.0, 0.0}; // the four grid-wide sums as the single-GPU exchange hands them over (scalars)
-    if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec)
-           : !persist_exchange<NH, EB>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk, s_part, Sx))
+    if (single_wg)
+        persist_single_workgroup<NH>(s_S, Sx, hq);
+    else if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec)
+                : !persist_exchange<NH, EB>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk, s_part, Sx))
         return;
 
     const double c0 = P.c0, nu = P.nu, h = P.h;
@@ -1434,6 +1456,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         if (tid < 2)
             put_granules(P.recg + 4 * (2 * ((int64_t)par * cgrid + blockIdx.x) + tid), epoch,
                          tid == 0 ? make_double2(acc[0], acc[1]) : make_double2(acc[2], acc[3]));
+        if (single_wg && tid < 2) ((double2 *)s_S)[tid] = tid == 0 ? make_double2(acc[0], acc[1]) : make_double2(acc[2], acc[3]);
 #ifdef MAG_PERSIST_STAMPS
         if (stamping) {
             const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();
@@ -1470,8 +1493,10 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
 #ifdef MAG_PERSIST_STAMPS
         unsigned long long *xs_ = stamp_sum + kStampPhases + 2; // (LDS as well: no stack object, no scratch in the diagnostic build)
         if (stamping) xs_[0] = xs_[1] = xs_[2] = xs_[3] = xs_[4] = 0;
-        if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec, stamping ? xs_ : nullptr)
-               : !persist_exchange<NH, EB>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk, s_part, Sx, stamping ? xs_ : nullptr))
+        if (single_wg)
+            persist_single_workgroup<NH>(s_S, Sx, hq);
+        else if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec, stamping ? xs_ : nullptr)
+                    : !persist_exchange<NH, EB>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk, s_part, Sx, stamping ? xs_ : nullptr))
             return;
         if (stamping) { // inside the exchange: wait before the first sweep / sweeps until complete / record reduction
             stamp_sum[4] += xs_[0] - stamp_last;
@@ -1483,8 +1508,10 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
             stamp_sum[13] += end_ - xs_[3];
         }
 #else
-        if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec)
-               : !persist_exchange<NH, EB>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk, s_part, Sx))
+        if (single_wg)
+            persist_single_workgroup<NH>(s_S, Sx, hq);
+        else if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec)
+                    : !persist_exchange<NH, EB>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk, s_part, Sx))
             return;
 #endif
     }
@@ -1737,6 +1764,16 @@ void persist_launch(const PersistParams &P, int32_t B, int32_t grid, int threads
 #ifdef MAG_PERSIST_768
     if (threads == 768) return persist_launch_t<768>(P, B, grid, lds, 0, s);
 #endif
+    // The whole mesh in one workgroup: the instantiation without an exchange -- for the edge-block instantiations, whose tiles read
+    // every sibling's node through LDS.  (The triangle walk keeps halo COPIES of sibling nodes in tiles whose rows do not fit its
+    // registers, and advances them with q fetched from the granules: it goes through the exchange even alone on the grid.)
+    if (grid == 1 && P.nranks == 1 && B == 512 && eb_mode != 0) {
+        if (eb_mode == 2)
+            k_cg_persist<512, false, 512, 2, true><<<1, 512, lds, s>>>(P);
+        else
+            k_cg_persist<512, false, 512, 1, true><<<1, 512, lds, s>>>(P);
+        return;
+    }
     persist_launch_t<512>(P, B, grid, lds, eb_mode, s);
 }
 
