@@ -118,6 +118,15 @@ __device__ inline double wave_sum_dpp(double v)
 // 0-6 the phases, 7 sweeps taken; detail (round 4): 8 wave trees of the sums, 9 the sums' barrier (waiting for the workgroup's
 // slowest wave), 10 cross-wave chain + record store, 11 the deferred x update, 12 after this wave's sweeps: waiting for the
 // workgroup's other waves, 13 record reduction + its barrier
+#ifndef MAG_PERSIST_OPAQUE
+#define MAG_PERSIST_OPAQUE 1 // the thread index behind an empty asm: 0 nowhere, 1 in the overflow instantiation, 2 everywhere
+#endif
+#ifndef MAG_PERSIST_OPAQUE_XCHG
+#define MAG_PERSIST_OPAQUE_XCHG 1
+#endif
+#ifndef MAG_PERSIST_OPAQUE_SUM
+#define MAG_PERSIST_OPAQUE_SUM 1
+#endif
 constexpr int kStampPhases = 14;
 
 // a lane's double moved by a DPP control (lanes without a source read 0)
@@ -133,12 +142,13 @@ __device__ inline double dpp_move_f64(double v)
 // thread's halo nodes, swept together until every tag matches; then the records are summed in one fixed two-level
 // order (chunks of eight workgroups, then the chunks) so that all workgroups hold the same bits.  grid <= 256.
 // Returns false when the spin budget runs out (some workgroup is not running): the timeout word is set for the host.
-template <int NH, bool EB = false>
+template <int NH, bool EB = false, bool OPQ = false>
 __device__ inline bool persist_exchange(const PersistParams &P, int par, unsigned epoch, const int32_t (&hg)[NH],
                                         double2 (&hq)[NH], double *s_S, double2 *s_rec, double *s_chunk, double *s_part,
                                         double (&Sx)[4], unsigned long long *stamp = nullptr)
 {
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
+    if (OPQ && MAG_PERSIST_OPAQUE_XCHG) asm volatile("" : "+v"(tid)); // (recomputed LDS addresses instead of hoisted and spilled ones: see persist_block_sum)
     const int grid = gridDim.x;
     gu32 *tmo = (gu32 *)P.sync + 9;
     // One sweep fetches what is still missing of both: a 16-byte piece of the records per thread and the q of this
@@ -713,14 +723,20 @@ __device__ inline void persist_comm_loop(const PersistParams &P, double *s_S, do
 // adds them with one 16-byte read and a four-step tree per row -- 7 + 5 additions on the critical path where there were
 // 24 + 7, a fixed order of additions as before (so every run gives the same bits; they are not round 3's bits).
 constexpr int kPersistPartDoubles = 128; // s_part: four sums x (8 waves x 4 rows)
-template <int THREADS>
+template <int THREADS, bool OPQ = false>
 __device__ inline void persist_block_sum(double (&acc)[4], double *s_red, double *s_part,
                                          [[maybe_unused]] unsigned long long *sub = nullptr)
 {
     constexpr int kPersistThreads = THREADS;
     constexpr int NWV = kPersistThreads / 64;
     if (NWV == 8) {
-        const int l = threadIdx.x & 63;
+        // (tx: the thread index behind an empty asm -- the LDS addresses below are then recomputed in every iteration, three
+        // instructions each.  Taken from threadIdx.x directly they are loop-invariant: the compiler hoisted them out of the CG
+        // loop, had no registers to keep them in -- the edge-block kernel sits at 256 of 256 -- and spilled them: nine
+        // scratch reloads per iteration, each behind an s_waitcnt vmcnt(0), i.e. behind the granule stores in flight.)
+        int tx = threadIdx.x;
+        if (OPQ && MAG_PERSIST_OPAQUE_SUM) asm volatile("" : "+v"(tx));
+        const int l = tx & 63;
         const bool odd = (l & 1) != 0, two = (l & 2) != 0;
         // level 1, lanes l and l ^ 1 (quad_perm [1, 0, 3, 2]): an even lane keeps sums 0, 1 and hands over 2, 3; an odd lane the reverse
         const double ka = odd ? acc[2] : acc[0], kb = odd ? acc[3] : acc[1];
@@ -731,7 +747,7 @@ __device__ inline void persist_block_sum(double (&acc)[4], double *s_red, double
         double v = k2 + dpp_move_f64<0x4E>(s2); // lane l of a quad now holds the quad's total of sum {0, 2, 1, 3}[l & 3]
         v += dpp_move_f64<0x114>(v);            // row_shr:4
         v += dpp_move_f64<0x118>(v);            // row_shr:8: lanes 12-15 of every row hold the row's totals
-        if ((l & 15) >= 12) s_part[(((l & 1) << 1) | ((l >> 1) & 1)) * 32 + (threadIdx.x >> 6) * 4 + (l >> 4)] = v;
+        if ((l & 15) >= 12) s_part[(((l & 1) << 1) | ((l >> 1) & 1)) * 32 + (tx >> 6) * 4 + (l >> 4)] = v;
 #ifdef MAG_PERSIST_STAMPS
         if (sub) sub[0] = __builtin_amdgcn_s_memrealtime(); // wave trees done, at the barrier
 #endif
@@ -739,7 +755,7 @@ __device__ inline void persist_block_sum(double (&acc)[4], double *s_red, double
 #ifdef MAG_PERSIST_STAMPS
         if (sub) sub[1] = __builtin_amdgcn_s_memrealtime(); // every wave has arrived
 #endif
-        if (threadIdx.x < 64) { // row c of wave 0 adds sum c's 32 partials: two per lane, then a tree over the row
+        if (tx < 64) { // row c of wave 0 adds sum c's 32 partials: two per lane, then a tree over the row
             const double2 pr = ((const double2 *)(s_part + (l >> 4) * 32))[l & 15];
             double t = pr.x + pr.y;
             t += dpp_move_f64<0x111>(t);
@@ -820,6 +836,10 @@ constexpr bool kPersistEdgeBlocks = MAG_PERSIST_EDGE_BLOCKS != 0; // edge blocks
 #endif
 constexpr int kPersistBlockEntries = MAG_PERSIST_NB; // block entries per node: a closed fan of valence 6 is exactly six blocks
 constexpr int kPersistNh = 2;   // halo entries per thread: a workgroup's tiles may carry 2 * THREADS halo nodes in all
+#ifndef MAG_PERSIST_ONE_TILE
+#define MAG_PERSIST_ONE_TILE 1
+#endif
+constexpr bool kPersistOneTile = MAG_PERSIST_ONE_TILE != 0;
 constexpr int persist_npt(int threads) { return threads == 768 ? 3 : 4; } // nodes per lane
 
 // Phase stamps (diagnostic build only: -DMAG_PERSIST_STAMPS, scripts/persist_phases.sh): lane 0 of every workgroup reads
@@ -878,12 +898,16 @@ __device__ inline void persist_single_workgroup(double *s_S, double (&Sx)[4], do
 // of their nodes with seven neighbours: blocks beyond the six in registers sit in an LDS pool of 32-byte records).
 // ONE: the single-workgroup instantiation (the mesh is at most four tiles: persist_single_workgroup).  An instantiation of its
 // own, not a branch: the edge-block kernel sits at 256 of 256 registers, and a conditional exchange made the allocator spill 24.
-template <int B, bool MG, int THREADS, int EBM, bool ONE = false>
+// NPTX: nodes per lane when not the shape's four -- 1: ONE TILE PER WORKGROUP, what a mesh of at most 256 tiles runs as (config 2:
+// 99 tiles).  The general instantiation carries three dead node slots through every loop there, and their registers (the
+// blocks alone are 36 per slot) are what puts it at the 256-register limit.
+template <int B, bool MG, int THREADS, int EBM, bool ONE = false, int NPTX = 0>
 __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
 {
     constexpr int kPersistThreads = THREADS;
-    constexpr int NPT = persist_npt(THREADS);
+    constexpr int NPT = NPTX ? NPTX : persist_npt(THREADS);
     constexpr bool EB = EBM != 0, OV = EBM == 2;
+    constexpr bool OPQ = MAG_PERSIST_OPAQUE == 2 || (MAG_PERSIST_OPAQUE == 1 && OV); // see persist_block_sum
     constexpr int SB = NPT * THREADS / B - 1; // bias of the workgroup-relative ring entries, in tile images (see the remap below)
     extern __shared__ __attribute__((aligned(16))) double2 smem[];
     const int tid = threadIdx.x;
@@ -1171,7 +1195,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         }
     }
     if (blockIdx.x == 0 && tid == 0) acc[1] = 1.0; // "p.q" > 0: alpha finite, multiplies q = 0
-    persist_block_sum<THREADS>(acc, s_red, s_part);
+    persist_block_sum<THREADS, OPQ>(acc, s_red, s_part);
     int par = 0;
     unsigned epoch = tag0; // the tags of successive exchanges
     constexpr bool single_wg = ONE && !MG; // the whole mesh in this workgroup: no exchange at all
@@ -1184,7 +1208,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
     if (single_wg)
         persist_single_workgroup<NH>(s_S, Sx, hq);
     else if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec)
-                : !persist_exchange<NH, EB>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk, s_part, Sx))
+                : !persist_exchange<NH, EB, OPQ>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk, s_part, Sx))
         return;
 
     const double c0 = P.c0, nu = P.nu, h = P.h;
@@ -1446,9 +1470,9 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         MAG_STAMP(2) // ring walks of this wave's nodes, q published
 #ifdef MAG_PERSIST_STAMPS
         unsigned long long *sub_ = stamp_sum + kStampPhases + 8;
-        persist_block_sum<THREADS>(acc, s_red, s_part, stamping ? sub_ : nullptr);
+        persist_block_sum<THREADS, OPQ>(acc, s_red, s_part, stamping ? sub_ : nullptr);
 #else
-        persist_block_sum<THREADS>(acc, s_red, s_part);
+        persist_block_sum<THREADS, OPQ>(acc, s_red, s_part);
 #endif
         par ^= 1;
         ++epoch;
@@ -1496,7 +1520,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         if (single_wg)
             persist_single_workgroup<NH>(s_S, Sx, hq);
         else if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec, stamping ? xs_ : nullptr)
-                    : !persist_exchange<NH, EB>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk, s_part, Sx, stamping ? xs_ : nullptr))
+                    : !persist_exchange<NH, EB, OPQ>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk, s_part, Sx, stamping ? xs_ : nullptr))
             return;
         if (stamping) { // inside the exchange: wait before the first sweep / sweeps until complete / record reduction
             stamp_sum[4] += xs_[0] - stamp_last;
@@ -1511,7 +1535,7 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
         if (single_wg)
             persist_single_workgroup<NH>(s_S, Sx, hq);
         else if (MG ? !persist_exchange_mg<NH>(P, par, epoch, hg, hq, s_S, s_rec)
-                    : !persist_exchange<NH, EB>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk, s_part, Sx))
+                    : !persist_exchange<NH, EB, OPQ>(P, par, epoch, hg, hq, s_S, s_rec, s_chunk, s_part, Sx))
             return;
 #endif
     }
@@ -1772,6 +1796,10 @@ void persist_launch(const PersistParams &P, int32_t B, int32_t grid, int threads
             k_cg_persist<512, false, 512, 2, true><<<1, 512, lds, s>>>(P);
         else
             k_cg_persist<512, false, 512, 1, true><<<1, 512, lds, s>>>(P);
+        return;
+    }
+    if (kPersistOneTile && P.tiles_per_wg == 1 && P.nranks == 1 && B == 512 && eb_mode == 1) {
+        k_cg_persist<512, false, 512, 1, false, 1><<<grid, 512, lds, s>>>(P);
         return;
     }
     persist_launch_t<512>(P, B, grid, lds, eb_mode, s);
