@@ -108,6 +108,12 @@ def build_problem(workload, n_gpus):
     if workload == "multihole16m":
         n = meshgen.grid_for_triangles(16e6, np.pi * 0.25 ** 2)
         return meshgen.config_fixed_left_pull_right(meshgen.multi_hole(n, 4, 0.25)), f"multi-hole {n}^2"
+    if workload.startswith("plate:") or workload.startswith("frontal:"):  # size sweeps: plate:<cells per side>, frontal:<pitch>
+        if n_gpus != 1:
+            raise SystemExit(f"{workload} is a single-GPU workload")
+        kind, n = workload.split(":")
+        mesh = meshgen.plate(int(n), int(n)) if kind == "plate" else meshgen.frontal_like(int(n), 0.4, 1)
+        return meshgen.config_fixed_left_pull_right(mesh), f"{kind} {n}"
     raise SystemExit(f"unknown workload {workload}")
 
 
