@@ -196,7 +196,8 @@ typedef struct mag_stats {
                                edge-block instantiation WITH OVERFLOW (rows that are one fan of any length -- gmsh-type
                                meshes: the blocks beyond six per node in an LDS pool; single GPU); 0 when it walked the
                                triangles (nodes with several fans, or a pool that does not fit)                     */
-    int32_t reserved0;
+    int32_t tiles_per_workgroup; /* cg_kernel 2 only: tiles each workgroup of the on-chip kernel held (1-4 of 512 nodes; up
+                                    to three on one GPU run the instantiation with that many node slots per lane)      */
 } mag_stats;
 
 /* ---- lifecycle ------------------------------------------------------- */

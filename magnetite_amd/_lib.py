@@ -62,7 +62,7 @@ class Stats(C.Structure):
                 ("ms_bc", C.c_double), ("ms_cg", C.c_double), ("ms_post", C.c_double), ("ms_total", C.c_double),
                 ("best_iteration", C.c_int64), ("termination", C.c_int32), ("persist_timeout", C.c_int32),
                 ("exchange_timeout", C.c_int32), ("best_param_mismatch", C.c_int32),
-                ("edge_blocks", C.c_int32), ("reserved0", C.c_int32)]
+                ("edge_blocks", C.c_int32), ("tiles_per_workgroup", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -2060,6 +2060,7 @@ int mag_run(mag_ctx *ctx)
     ctx->have_run = true;
     st.persist_timeout = ctx->persist_timed_out ? 1 : 0;
     st.edge_blocks = ctx->cg_kernel == 2 ? ctx->edge_blocks : 0;
+    st.tiles_per_workgroup = ctx->cg_kernel == 2 ? ctx->persist_k : 0;
     st.exchange_timeout = ctx->exchange_timed_out ? 1 : 0;
     if (st.breakdown)
         return fail(ctx, MAG_ERR_NOT_CONVERGED, "Conjugate Gradient error: non-finite residual after %lld iterations",

@@ -1161,6 +1161,41 @@ def test_on_chip_edge_blocks_with_overflow_match_the_oracle_and_the_triangle_wal
         assert rel(out["u"], plain["u"]) <= 1e-12 and out["iterations"] == plain["iterations"]
 
 
+@pytest.mark.parametrize("case", ["blocks_k2", "blocks_k3", "overflow_k3", "blocks_one_wg_1", "blocks_one_wg_2", "blocks_one_wg_3",
+                                  "overflow_one_wg_1", "overflow_one_wg_2", "overflow_one_wg_3"])
+def test_on_chip_node_slots_per_lane_follow_the_tiles_per_workgroup(built, case, monkeypatch):
+    """A workgroup of the on-chip kernel that holds fewer than four 512-node tiles runs the instantiation with as many
+    node slots per lane (k_cg_persist's NPTX; config 2 runs one tile per workgroup): two and three tiles per workgroup on
+    a grid of several workgroups, and the single-workgroup instantiation at one, two and three tiles, for the edge-block
+    kernel and its overflow variant.  (One tile per workgroup on a grid is what every mid-size case of the tests above
+    runs; two tiles with overflow records is their `frontal_two_tiles_per_wg`.)  Against the oracle."""
+    kind, rest = case.split("_", 1)
+    if rest.startswith("k"):
+        k = int(rest[1:])
+        monkeypatch.setenv("MAG_TUNE_PERSIST_K", str(k))
+        mesh = meshgen.shuffle(meshgen.plate_with_holes(120), 3) if kind == "blocks" else meshgen.frontal_like(110, 0.4, 9)
+        one_wg = False
+    else:
+        k = int(rest[-1])
+        n = {1: 20, 2: 29, 3: 36}[k]  # 441, 900, 1369 nodes (plate); the lattice of frontal_like about as many
+        mesh = meshgen.plate(n) if kind == "blocks" else meshgen.frontal_like({1: 19, 2: 27, 3: 34}[k], 0.4, k)
+        one_wg = True
+    p = meshgen.config_fixed_left_pull_right(mesh)
+    tiles = (p.mesh.num_nodes + 511) // 512
+    assert (tiles == k) if one_wg else (tiles > 2 * k), (case, p.mesh.num_nodes)
+    ref = oracle_run(p)
+    with Context(device=0, tile_nodes=512) as c:
+        out = c.solve(p)
+        st = c.stats()
+        again = c.solve(p)
+    assert st["cg_kernel"] == 2 and st["edge_blocks"] == (1 if kind == "blocks" else 2), (case, st)
+    assert st["tiles_per_workgroup"] == k, (case, st["tiles_per_workgroup"])
+    assert out["converged"] == 1 and abs(out["iterations"] - ref["iterations"]) <= max(3, ref["iterations"] // 50), case
+    for key in ("u", "f", "stress"):
+        assert rel(out[key], ref[key]) <= TOL_U, (case, key)
+    assert np.array_equal(out["u"], again["u"])
+
+
 def test_on_chip_edge_blocks_are_refused_where_a_row_does_not_fit(built, monkeypatch):
     """A node whose triangles form TWO fans (a plate with one cell pair removed so that two corner cells touch only at a
     node; the hanging midpoints around the valence-12 hub of _plate_with_a_hub) keeps the whole mesh on the triangle walk
