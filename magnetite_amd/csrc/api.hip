@@ -1349,7 +1349,9 @@ int cg_phase_persist(mag_ctx *ctx)
         HIPCHK(hipStreamSynchronize(s));
         if (fan_flags == 0) eb_mode = 1;
         const char *no_ovf = getenv("MAG_TUNE_PERSIST_NO_OVERFLOW");
-        if (((fan_flags == 1 && !(no_ovf && atoi(no_ovf))) || (fan_flags == 0 && getenv("MAG_TUNE_PERSIST_FORCE_OVERFLOW"))) && !mg) {
+        const char *mgo = getenv("MAG_TUNE_PERSIST_MG_OVERFLOW"); // =0: several ranks keep the triangle walk on such meshes
+        if (((fan_flags == 1 && !(no_ovf && atoi(no_ovf))) || (fan_flags == 0 && getenv("MAG_TUNE_PERSIST_FORCE_OVERFLOW"))) &&
+            !(mg && mgo && atoi(mgo) == 0)) {
             // per-node overflow counts -> scan -> the limits the LDS must meet
             const int nb = magk::persist_block_entries();
             HIPCHK(ctx->ovf_cnt.reserve(4 * ((size_t)npad + 1)));
@@ -1358,7 +1360,13 @@ int cg_phase_persist(mag_ctx *ctx)
             if (int rc = scan_i32(ctx, ctx->ovf_cnt.as<int32_t>(), ctx->ovf_off.as<int32_t>(), (size_t)npad + 1)) return rc;
             int32_t *lim_d = ctx->ovf_cnt.as<int32_t>(); // (the counts are not needed after the scan: their first words hold the limits)
             HIPCHK(hipMemsetAsync(lim_d, 0, 8, s));
-            magk::ovf_limits(ctx->ovf_off.as<int32_t>(), ctx->B, ctx->persist_k, ctx->t0, ctx->t1, lim_d, s);
+            // (several ranks: the limits over EVERY rank's workgroups -- the ordering phase is replicated --, so that all ranks
+            // reach the same decision)
+            for (int r_ = 0; r_ < ctx->comm.nranks; ++r_) {
+                const int32_t ta = mg ? (int32_t)(((int64_t)ctx->T * r_) / ctx->comm.nranks) : ctx->t0;
+                const int32_t tb = mg ? (int32_t)(((int64_t)ctx->T * (r_ + 1)) / ctx->comm.nranks) : ctx->t1;
+                magk::ovf_limits(ctx->ovf_off.as<int32_t>(), ctx->B, ctx->persist_k, ta, tb, lim_d, s);
+            }
             int32_t lim[3] = {0, 0, 0};
             HIPCHK(hipMemcpyAsync(lim, lim_d, 8, hipMemcpyDeviceToHost, s));
             HIPCHK(hipMemcpyAsync(&lim[2], ctx->ovf_off.as<int32_t>() + npad, 4, hipMemcpyDeviceToHost, s));
@@ -1366,7 +1374,7 @@ int cg_phase_persist(mag_ctx *ctx)
             const int32_t pool = ((lim[0] + 1 + 7) / 8) * 8; // + record 0, the zero block
             // 12 bits of pool position and 4 bits of count per node slot; the kernel's static LDS on top of the dynamic
             if (lim[0] + 1 <= 4095 && lim[1] <= 15 &&
-                magk::persist_lds_bytes(ctx->B, ctx->cap, ctx->persist_maxh, magk::persist_threads(), 2, pool) + 256 <= 160 * 1024) {
+                magk::persist_lds_bytes(ctx->B, ctx->cap, ctx->persist_maxh, magk::persist_threads(), 2, pool, mg) + 256 <= 160 * 1024) {
                 eb_mode = 2;
                 P.pool_cap = pool;
                 HIPCHK(ctx->ovf_rec.reserve(32 * (size_t)std::max(lim[2], 1)));

@@ -923,7 +923,8 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
     double *s_S = s_red + 4 * (kPersistThreads / 64);
     double *s_chunk = s_S + 4;
     double *s_part = s_chunk + 4 * 32; // persist_block_sum: the rows' partials of the four sums
-    [[maybe_unused]] double2 *s_pool = (double2 *)(s_part + kPersistPartDoubles); // overflow records (OV): two double2 each
+    // overflow records (OV): two double2 each; several ranks: behind the interface words (s_opk, below)
+    [[maybe_unused]] double2 *s_pool = (double2 *)(s_part + kPersistPartDoubles) + (MG ? NPT * THREADS / 4 : 0);
     // slot s of this lane: local node s * THREADS + tid, in local tile (s * THREADS + tid) / B (a scalar: wave-uniform)
     auto t_loc = [&](int s) { return __builtin_amdgcn_readfirstlane((s * THREADS + tid) / B); };
     auto t_lt = [&](int s) { return (s * THREADS + tid) % B; };
@@ -1754,7 +1755,12 @@ template <int THREADS>
 static void persist_launch_t(const PersistParams &P, int32_t B, int32_t grid, size_t lds, int eb_mode, hipStream_t s)
 {
     if (P.nranks > 1) {
-        if (eb_mode == 1) {
+        if (eb_mode == 2) {
+            if (B == 256)
+                k_cg_persist<256, true, THREADS, 2><<<grid, THREADS, lds, s>>>(P);
+            else
+                k_cg_persist<512, true, THREADS, 2><<<grid, THREADS, lds, s>>>(P);
+        } else if (eb_mode == 1) {
             if (B == 256)
                 k_cg_persist<256, true, THREADS, 1><<<grid, THREADS, lds, s>>>(P);
             else
@@ -1780,10 +1786,10 @@ static void persist_launch_t(const PersistParams &P, int32_t B, int32_t grid, si
 }
 
 // eb_mode: 1 every row of the mesh qualifies for the edge-block instantiation (ring16's flag), 2 with overflow records in LDS
-// (single GPU; the host has checked the pool against the LDS), 0 the triangle walk
+// (the host has checked the pool against the LDS), 0 the triangle walk
 void persist_launch(const PersistParams &P, int32_t B, int32_t grid, int threads, int eb_mode, hipStream_t s)
 {
-    if (!kPersistEdgeBlocks || (eb_mode == 2 && P.nranks > 1)) eb_mode = 0;
+    if (!kPersistEdgeBlocks) eb_mode = 0;
     const size_t lds = persist_lds_bytes(B, P.cap, P.maxh, threads, eb_mode, P.pool_cap, P.nranks > 1);
 #ifdef MAG_PERSIST_768
     if (threads == 768) return persist_launch_t<768>(P, B, grid, lds, 0, s);

@@ -48,5 +48,8 @@ echo "phases done" >> "$OUT/progress.txt"
 : > "$OUT/multirank_rehearsals.jsonl"
 MAG_TUNE_PERSIST_K=4 python3 bench.py --gpus 2 --share-gpu --partition strong --workload hole1m --exchange inboxes --no-cpu-baseline --no-hbm-resident --steps 3 --warmup 1 --check-fixture >> "$OUT/multirank_rehearsals.jsonl" 2>> "$OUT/multirank_rehearsals.err"
 MAG_TUNE_PERSIST_K=4 MAG_TUNE_PERSIST_MG_BLOCKS=0 python3 bench.py --gpus 2 --share-gpu --partition strong --workload hole1m --exchange inboxes --no-cpu-baseline --no-hbm-resident --steps 3 --warmup 1 --check-fixture >> "$OUT/multirank_rehearsals.jsonl" 2>> "$OUT/multirank_rehearsals.err"
+# the unstructured 1M mesh across two ranks: edge blocks with overflow records (round 4) and the triangle walk; its fixture stops at 1e-10
+MAG_TUNE_PERSIST_K=4 python3 bench.py --gpus 2 --share-gpu --partition strong --workload frontal1m --tol 1e-10 --exchange inboxes --no-cpu-baseline --no-hbm-resident --no-unstructured --steps 2 --warmup 1 --check-fixture >> "$OUT/multirank_rehearsals.jsonl" 2>> "$OUT/multirank_rehearsals.err"
+MAG_TUNE_PERSIST_K=4 MAG_TUNE_PERSIST_MG_OVERFLOW=0 python3 bench.py --gpus 2 --share-gpu --partition strong --workload frontal1m --tol 1e-10 --exchange inboxes --no-cpu-baseline --no-hbm-resident --no-unstructured --steps 2 --warmup 1 --check-fixture >> "$OUT/multirank_rehearsals.jsonl" 2>> "$OUT/multirank_rehearsals.err"
 python3 bench.py --gpus 4 --share-gpu --partition strong --workload plate4m --exchange inboxes --cg-variant 1 --no-cpu-baseline --no-hbm-resident --steps 1 --warmup 1 --check-fixture >> "$OUT/multirank_rehearsals.jsonl" 2>> "$OUT/multirank_rehearsals.err"
 echo "all done" >> "$OUT/progress.txt"

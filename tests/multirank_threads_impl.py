@@ -159,6 +159,44 @@ def test_eight_ranks_on_chip_edge_blocks(case, monkeypatch):
     assert all(o["edge_blocks"] == 0 and o["cg_kernel"] == 2 for outs in results for o in outs)
 
 
+def test_eight_ranks_on_chip_edge_blocks_with_overflow_on_an_unstructured_mesh(built, monkeypatch):
+    """What the reference's mesher hands `solver::run` (mesher.rs:501-506) is unstructured: across ranks such a mesh now runs
+    the edge-block instantiation with overflow records too (edge_blocks == 2; until round 4 it fell to the triangle walk as
+    soon as there was a second rank), every rank deciding from the pool limits of ALL ranks' workgroups.  Forced to two and
+    three tiles per workgroup as well (sibling slots inside the pool's entries), and with MAG_TUNE_PERSIST_MG_OVERFLOW=0:
+    the walk."""
+    p = meshgen.config_fixed_left_pull_right(meshgen.shuffle(meshgen.frontal_like(300, 0.4, 11), 4))
+    assert p.mesh.num_nodes >= 8 * 6 * 512
+    ref = oracle.run(p.xy_flat, p.conn_flat, p.u_known, p.u_in, p.f_in, p.youngs_modulus, p.poisson_ratio,
+                     p.part_thickness, path="sparse", stop_mode=oracle.STOP_REL, tol=1e-9)
+    with Context(device=0, stop_mode=_lib.MAG_STOP_REL, tol=1e-9) as c:
+        single = c.solve(p)
+        assert c.stats()["edge_blocks"] == 2
+    case = (p, ref, single)
+    for k, mode in ((None, 2), ("2", 2), ("3", 2), (None, 0)):
+        if k:
+            monkeypatch.setenv("MAG_TUNE_PERSIST_K", k)
+        else:
+            monkeypatch.delenv("MAG_TUNE_PERSIST_K", raising=False)
+        if mode == 0:
+            monkeypatch.setenv("MAG_TUNE_PERSIST_MG_OVERFLOW", "0")
+        results = run_ranks(p, inboxes=True, solves=2 if k is None and mode else 1, cg_variant=2, tile_nodes=512,
+                            stop_mode=_lib.MAG_STOP_REL, tol=1e-9)
+        assert all(o["edge_blocks"] == mode and o["cg_kernel"] == 2 and o["exchange"] == 2 for outs in results for o in outs), \
+            (k, mode, [(o["edge_blocks"], o["cg_kernel"]) for outs in results for o in outs])
+        for rank, outs in enumerate(results):
+            for out in outs:
+                assert out["converged"] == 1
+                assert abs(out["iterations"] - ref["iterations"]) <= max(3, ref["iterations"] // 50)
+                # (a relative stop at 1e-9 leaves two solves that far apart, reactions and stresses at ~1e-8)
+                assert rel(out["u"], ref["u"]) <= 1e-8 and rel(out["u"], single["u"]) <= 1e-8
+                kn = p.u_known == 1
+                assert rel(out["f"][kn], ref["f"][kn]) <= 1e-7 and rel(out["stress"], ref["stress"]) <= 1e-7
+            assert all(np.array_equal(o["u"], outs[0]["u"]) for o in outs[1:])
+        for outs in results[1:]:
+            assert np.array_equal(outs[0]["u"], results[0][0]["u"])
+
+
 def test_eight_ranks_agree_to_fall_back(case, monkeypatch):
     """MAG_TUNE_PERSIST_SPIN=0: every wait of the on-chip kernels gives up at once; the ranks agree on it through one
     all-reduce of their failure flags and all redo the solve with the streaming kernels -- and say so in their stats"""
