@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define MAG_ABI_VERSION 4 /* 3: mag_stats gained exchange_timeout, best_param_mismatch; 4: edge_blocks */
+#define MAG_ABI_VERSION 4 /* 3: mag_stats gained exchange_timeout, best_param_mismatch; 4: edge_blocks (and, in the
+                             reserved word behind it, tiles_per_workgroup) */
 
 /* solver.rs:17-19 */
 #define MAG_DOF 2
@@ -194,7 +195,7 @@ typedef struct mag_stats {
                                triangles folded into at most six symmetric 2 x 2 blocks held in registers: meshes whose
                                nodes all carry one fan of at most six triangles, closed, or five, open); 2 when it ran the
                                edge-block instantiation WITH OVERFLOW (rows that are one fan of any length -- gmsh-type
-                               meshes: the blocks beyond six per node in an LDS pool; single GPU); 0 when it walked the
+                               meshes: the blocks beyond six per node in an LDS pool); 0 when it walked the
                                triangles (nodes with several fans, or a pool that does not fit)                     */
     int32_t tiles_per_workgroup; /* cg_kernel 2 only: tiles each workgroup of the on-chip kernel held (1-4 of 512 nodes; up
                                     to three on one GPU run the instantiation with that many node slots per lane)      */
