@@ -28,7 +28,7 @@ with Context(device=0, stop_mode=_lib.MAG_STOP_REL, tol=1e-8, cg_variant=2) as c
     c.upload_problem(prob)
     c.run(); c.run()
     st = c.stats()
-print(json.dumps({k: st[k] for k in ("iterations", "ms_cg", "cg_kernel", "num_tiles", "persist_timeout", "edge_blocks")}))
+print(json.dumps({k: st[k] for k in ("iterations", "ms_cg", "cg_kernel", "num_tiles", "persist_timeout", "edge_blocks", "tiles_per_workgroup")}))
 """ % ROOT
 
 
@@ -75,7 +75,7 @@ def main():
             lo = [min(w[k] for w in per_wg) for k in range(7)]
             hi = [max(w[k] for w in per_wg) for k in range(7)]
             sweeps = sum(r[7] / r[-1] for r in rows) / n
-            d = {"workload": workload, "threads": threads, "nodes_per_lane": 3 if threads == 768 else 4, "workgroups": n,
+            d = {"workload": workload, "threads": threads, "node_slots_per_lane": st["tiles_per_workgroup"] if st["tiles_per_workgroup"] < 4 else (3 if threads == 768 else 4), "workgroups": n,
                  "iterations": plain["iterations"], "cg_kernel": plain["cg_kernel"], "edge_blocks": st["edge_blocks"],
                  "us_per_iteration_product_build": plain["ms_cg"] * 1e3 / plain["iterations"],
                  "us_per_iteration_stamped_build": st["ms_cg"] * 1e3 / st["iterations"],
