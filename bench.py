@@ -245,7 +245,7 @@ def roofline_streaming(kind, E, N, ms_op, pmc, tile):
                        bytes_spmv(E, N) + 48.0 * N, "12E+50N (SpMV, SURVEY 8d) + 48N (p read, p and x written)", ms_op, pmc)
 
 
-def roofline_onchip(E, N, iters, ms_cg, pmc, tile, edge_blocks=False):
+def roofline_onchip(E, N, iters, ms_cg, pmc, tile, edge_blocks=False, tiles_per_workgroup=None):
     """k_cg_persist keeps the CG state in registers and LDS: HBM only sees the per-iteration exchange, so an HBM roof
     says nothing about it.  Its largest counted resource is fp64 vector issue (PMC: SQ_ACTIVE_INST_VALU), so it is
     priced against the fp64 vector peak with the ALGORITHMIC flops of the iterations it ran; the counted utilisations
@@ -259,6 +259,8 @@ def roofline_onchip(E, N, iters, ms_cg, pmc, tile, edge_blocks=False):
                       else ("edge-block instantiation: six symmetric 2 x 2 blocks per node in registers" if edge_blocks
                             else "triangle-walk instantiation: cached triangle weights")),
          "edge_blocks": bool(edge_blocks), "edge_block_mode": int(edge_blocks),
+         # 512-node tiles per workgroup; below four the instantiation with that many node slots per lane runs (DESIGN R4.6)
+         "tiles_per_workgroup": tiles_per_workgroup,
          "bound": "valu-fp64", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
          "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "flops_per_launch": flops,
          "flops_formula": "(110E + 20N) x iterations (SURVEY 8d: ~110 flop per element-loop SpMV element + 10 flop per "
@@ -339,7 +341,8 @@ def unstructured_leg(device, tol, reps=3):
     mean_ms = sum(ms) / len(ms)
     return {"workload": f"frontal1m: {desc}, {E} triangles, {N} nodes, left edge fixed, right edge ux=delta; CG stop=rel tol={tol:g}",
             "elements": E, "nodes": N, "steps": reps, "ms_per_step": mean_ms, "value": E / (mean_ms * 1e-3), "unit": "elements/s",
-            "cg_kernel": int(st["cg_kernel"]), "edge_blocks": int(st["edge_blocks"]), "iterations": int(st["iterations"]),
+            "cg_kernel": int(st["cg_kernel"]), "edge_blocks": int(st["edge_blocks"]),
+            "tiles_per_workgroup": int(st.get("tiles_per_workgroup", 0)), "iterations": int(st["iterations"]),
             "us_per_iteration": st["ms_cg"] * 1e3 / max(int(st["iterations"]), 1), "converged": int(st["converged"]),
             "verify_rel_residual": verify, "fixture_parity": parity, "phases_ms": {k: st[k] for k in ("ms_order", "ms_csr_symbolic", "ms_assemble",
                                                                            "ms_bc", "ms_cg", "ms_post", "ms_total")},
@@ -612,7 +615,7 @@ def main():
             tile_key = "none"
         if kind == 2:
             roofline = roofline_onchip(Eloc, Nloc, iters, st["ms_cg"], load_pmc(f"{tile_key}:kernel2"), args.tile,
-                                       int(st.get("edge_blocks", 0)))
+                                       int(st.get("edge_blocks", 0)), int(st.get("tiles_per_workgroup", 0)) or None)
         elif kind == 4:  # fp32 leg: value terms halved (r, q, p, x in and out 64N, coordinates 8N, mask 1N); no timing
             # hook of its own, so the launch time is the CG phase / iterations (graph gaps and early exits included)
             roofline = kernel_line("k_cg_fused32<%d> (whole CG iteration in one launch, fp32 state)" % args.tile,

@@ -42,7 +42,8 @@ for seed in range(900, 900 + n):
     if kind == 3:
         mesh = _poisson_delaunay(int(rng.integers(3000, 16000)), seed)
     else:
-        mesh = meshgen.frontal_like(int(rng.integers(50, 150)), float(rng.uniform(0.3, 0.5)), seed)
+        # (every fifth lattice small enough for ONE workgroup of one to four tiles: the instantiation without an exchange)
+        mesh = meshgen.frontal_like(int(rng.integers(14, 42) if seed % 5 == 1 else rng.integers(50, 150)), float(rng.uniform(0.3, 0.5)), seed)
     if seed % 3 == 0:
         mesh = cut_holes(mesh, rng, int(rng.integers(1, 4)))
     if seed % 5 == 0:
@@ -51,13 +52,19 @@ for seed in range(900, 900 + n):
     p = (meshgen.config_fixed_left_point_load if seed % 2 else meshgen.config_fixed_left_pull_right)(mesh)
     ref = oracle.run(p.xy_flat, p.conn_flat, p.u_known, p.u_in, p.f_in, p.youngs_modulus, p.poisson_ratio,
                      p.part_thickness, path="sparse")
+    # tiles per workgroup: the library's choice, or forced to 2, 3, 4 (the instantiations with that many node slots per lane)
+    kk = (None, "2", "3", None, "4", None)[seed % 6]
+    if kk:
+        os.environ["MAG_TUNE_PERSIST_K"] = kk
+    else:
+        os.environ.pop("MAG_TUNE_PERSIST_K", None)
     with Context(device=0, tile_nodes=512, assemble_csr=(1, 0)[seed % 2]) as c:
         out = c.solve(p)
         st = c.stats()
         os.environ["MAG_TUNE_PERSIST_TRIANGLES"] = "1"
         walk = c.solve(p)
         del os.environ["MAG_TUNE_PERSIST_TRIANGLES"]
-    m = (st["cg_kernel"], st["edge_blocks"])
+    m = (st["cg_kernel"], st["edge_blocks"], st["tiles_per_workgroup"])
     modes[m] = modes.get(m, 0) + 1
     err = np.linalg.norm(out["u"] - ref["u"]) / np.linalg.norm(ref["u"])
     errw = np.linalg.norm(out["u"] - walk["u"]) / np.linalg.norm(walk["u"])
@@ -66,5 +73,5 @@ for seed in range(900, 900 + n):
     if not ok:
         bad.append((seed, mesh.name, p.mesh.num_nodes, err, errw, out["iterations"], ref["iterations"], m))
         print("MISS", bad[-1], flush=True)
-print(f"{n} problems in {time.time() - t0:.0f}s, (cg_kernel, edge_blocks) used {modes}, worst rel-L2 {worst:.3e}, failures: {bad}")
+print(f"{n} problems in {time.time() - t0:.0f}s, (cg_kernel, edge_blocks, tiles per workgroup) used {modes}, worst rel-L2 {worst:.3e}, failures: {bad}")
 sys.exit(1 if bad else 0)
