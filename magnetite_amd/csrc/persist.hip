@@ -1818,6 +1818,20 @@ void persist_launch(const PersistParams &P, int32_t B, int32_t grid, int threads
 #undef MAG_PERSIST_CASE
         return;
     }
+    // ... and across ranks (a 1M-triangle mesh over four or eight GPUs is one tile per workgroup)
+    if (kPersistOneTile && P.nranks > 1 && B == 512 && eb_mode != 0 && P.tiles_per_wg >= 1 && P.tiles_per_wg < 4) {
+        const int npt = P.tiles_per_wg;
+#define MAG_PERSIST_CASE(EBM_, NPTX_)                                                                                             \
+    if (eb_mode == EBM_ && npt == NPTX_) k_cg_persist<512, true, 512, EBM_, false, NPTX_><<<grid, 512, lds, s>>>(P)
+        MAG_PERSIST_CASE(1, 1);
+        MAG_PERSIST_CASE(1, 2);
+        MAG_PERSIST_CASE(1, 3);
+        MAG_PERSIST_CASE(2, 1);
+        MAG_PERSIST_CASE(2, 2);
+        MAG_PERSIST_CASE(2, 3);
+#undef MAG_PERSIST_CASE
+        return;
+    }
     persist_launch_t<512>(P, B, grid, lds, eb_mode, s);
 }
 
