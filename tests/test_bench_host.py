@@ -72,3 +72,17 @@ def test_pmc_counters_are_marked_stale_when_the_kernels_changed(built, tmp_path,
 def test_usable_cores_is_within_the_host():
     n = bench.usable_cores()
     assert 1 <= n <= (os.cpu_count() or 1)
+
+
+def test_size_sweep_workloads():
+    """`--workload plate:<cells per side>` / `frontal:<pitch>`: the size-sweep meshes of profiles/r04_persist_ab.txt (one,
+    two and three tiles per workgroup of the on-chip kernel); single-GPU workloads, like frontal1m."""
+    p, desc = bench.build_problem("plate:24", 1)
+    assert p.mesh.num_nodes == 25 * 25 and p.mesh.num_elements == 2 * 24 * 24 and desc == "plate 24"
+    q, desc = bench.build_problem("frontal:12", 1)
+    assert q.mesh.num_elements > 200 and desc == "frontal 12"
+    assert (q.u_known == 1).any() and (p.u_known == 1).any()
+    with pytest.raises(SystemExit):
+        bench.build_problem("plate:24", 2)
+    with pytest.raises(SystemExit):
+        bench.build_problem("no-such-workload", 1)
