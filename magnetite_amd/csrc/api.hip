@@ -109,6 +109,10 @@ struct mag_ctx {
     bool csr_full = true;    // the CSR held now covers every row (one rank, or a test entry point asked for all of K)
     bool want_full_csr = false; // mag_assemble_csr / mag_reduce_system on a multi-rank context: build all of K
     DevBuf local_node, ecnt, eoff;
+    // several ranks: the ordering phase's per-tile tables for the tiles this rank needs only (need_tile), decided per run
+    DevBuf need_tile, iface_mask;
+    bool order_sharded = false, order_allow_shard = false;
+    int32_t fan_flags_global = 3;
     // reduced system scratch
     DevBuf isfree, fidx, rcnt, rowoff, rp_ff, col_ff, val_ff, b_ff, rp_full, col_full;
     int64_t nf = 0, nz_ff = 0;
@@ -272,10 +276,10 @@ int ensure_order(mag_ctx *ctx)
     ctx->bitsN = ceil_log2(N);
     hipStream_t s = ctx->stream;
     const size_t nmax = (size_t)(N > 3 * E ? N : 3 * E);
-    HIPCHK(ctx->sK0.reserve(4 * nmax));
-    HIPCHK(ctx->sK1.reserve(4 * nmax));
-    HIPCHK(ctx->sV0.reserve(4 * nmax));
-    HIPCHK(ctx->sV1.reserve(4 * nmax));
+    HIPCHK(ctx->sK0.reserve(4 * nmax + 16));
+    HIPCHK(ctx->sK1.reserve(4 * nmax + 16));
+    HIPCHK(ctx->sV0.reserve(4 * nmax + 16));
+    HIPCHK(ctx->sV1.reserve(4 * nmax + 16));
     HIPCHK(ctx->small.reserve(8 * (4 * 256 + 4) + 64)); // bbox partials, bbox, {error flag, known count}
     HIPCHK(ctx->perm.reserve(4 * (size_t)N));
     HIPCHK(ctx->iperm.reserve(4 * (size_t)N));
@@ -321,12 +325,45 @@ int ensure_order(mag_ctx *ctx)
                       ctx->bP.as<double>(), s);
     ctx->b_from_order = true;
 
+    // ---- partition: contiguous tile ranges of the Hilbert order, identical arithmetic on every rank ----
+    const int R = ctx->comm.nranks, me = ctx->comm.rank;
+    auto tile_lo = [&](int s_) { return (int32_t)(((int64_t)T * s_) / R); };
+    ctx->t0 = tile_lo(me);
+    ctx->t1 = tile_lo(me + 1);
+    if (R > 1 && ctx->t1 <= ctx->t0) return fail(ctx, MAG_ERR_BAD_ARGS, "mesh has %d tiles, fewer than %d ranks", (int)T, R);
+    // Several ranks, inside mag_run (every rank is here: the phase then ends with two small all-reduces), K assembled from the
+    // rows a rank keeps: the tables below are built for the tiles this rank needs only (symbolic.hip, need_tiles).  Any other
+    // entry point -- and MAG_TUNE_SHARD_ORDER=0 -- builds them for the whole mesh, as every rank did until round 4.
+    const bool csr_rows = ctx->opt.assemble_csr != 0 || ctx->opt.cg_operator == MAG_OP_CSR;
+    const char *so = getenv("MAG_TUNE_SHARD_ORDER");
+    const bool sh = R > 1 && ctx->order_allow_shard && csr_rows && !ctx->want_full_csr && !(so && atoi(so) == 0) &&
+                    getenv("MAG_TUNE_FORCE_DIST") == nullptr;
+    ctx->order_sharded = sh;
     if (!counted) HIPCHK(hipMemsetAsync(ctx->deg.p, 0, 4 * ((size_t)N + 1), s));
+    if (sh) {
+        HIPCHK(ctx->need_tile.reserve((size_t)T + 64));
+        magk::need_tiles(ctx->conn.as<int32_t>(), E, ctx->iperm.as<int32_t>(), ctx->maskP.as<uint8_t>(), N, B, T, ctx->t0, ctx->t1,
+                         true, ctx->need_tile.as<uint8_t>(), s);
+        if (counted) magk::zero_unneeded_deg(ctx->need_tile.as<uint8_t>(), N, B, ctx->deg.as<int32_t>(), s);
+        magk::incidence_flags(ctx->conn.as<int32_t>(), E, ctx->iperm.as<int32_t>(), N, B, ctx->need_tile.as<uint8_t>(),
+                              ctx->sK1.as<int32_t>(), errflag, s);
+        if (int rc = scan_i32(ctx, ctx->sK1.as<int32_t>(), ctx->sV1.as<int32_t>(), (size_t)(3 * E) + 1)) return rc;
+        int32_t h_pairs = 0;
+        HIPCHK(hipMemcpyAsync(&h_pairs, ctx->sV1.as<int32_t>() + 3 * E, 4, hipMemcpyDeviceToHost, s));
+        magk::incidence_emit(ctx->conn.as<int32_t>(), E, ctx->iperm.as<int32_t>(), N, ctx->sV1.as<int32_t>(),
+                             ctx->sK0.as<uint32_t>(), ctx->sV0.as<uint32_t>(), counted ? nullptr : ctx->deg.as<int32_t>(), s);
+        HIPCHK(hipStreamSynchronize(s));
+        if (h_pairs > 0)
+            if (int rc = sort_u32(ctx, ctx->sK0.as<uint32_t>(), ctx->sK1.as<uint32_t>(), ctx->sV0.as<uint32_t>(),
+                                  ctx->inc.as<uint32_t>(), (size_t)h_pairs, ctx->bitsN))
+                return rc;
+    } else {
     magk::incidence_keys(ctx->conn.as<int32_t>(), E, ctx->iperm.as<int32_t>(), N, ctx->sK0.as<uint32_t>(),
                          ctx->sV0.as<uint32_t>(), counted ? nullptr : ctx->deg.as<int32_t>(), errflag, s);
     if (int rc = sort_u32(ctx, ctx->sK0.as<uint32_t>(), ctx->sK1.as<uint32_t>(), ctx->sV0.as<uint32_t>(),
                           ctx->inc.as<uint32_t>(), (size_t)(3 * E), ctx->bitsN))
         return rc;
+    }
     if (int rc = scan_i32(ctx, ctx->deg.as<int32_t>(), ctx->inc_off.as<int32_t>(), (size_t)N + 1)) return rc;
     HIPCHK(hipMemsetAsync(ctx->tile_cnt.as<int64_t>() + T, 0, 8, s));
     magk::tile_degree(ctx->deg.as<int32_t>(), N, B, T, ctx->tile_deg.as<int32_t>(), ctx->tile_cnt.as<int64_t>(), s);
@@ -391,17 +428,29 @@ int ensure_order(mag_ctx *ctx)
     }
     // ---- partition: contiguous tile ranges of the Hilbert order, identical arithmetic on every rank ----
     {
-        const int R = ctx->comm.nranks, me = ctx->comm.rank;
-        auto tile_lo = [&](int s_) { return (int32_t)(((int64_t)T * s_) / R); };
-        ctx->t0 = tile_lo(me);
-        ctx->t1 = tile_lo(me + 1);
         ctx->own0 = (int32_t)std::min<int64_t>((int64_t)ctx->t0 * B, N);
         ctx->own1 = (int32_t)std::min<int64_t>((int64_t)ctx->t1 * B, N);
         ctx->dist = R > 1 || getenv("MAG_TUNE_FORCE_DIST") != nullptr;
         ctx->n_iface = 0;
-        if (R > 1 && ctx->t1 <= ctx->t0)
-            return fail(ctx, MAG_ERR_BAD_ARGS, "mesh has %d tiles, fewer than %d ranks", (int)T, R);
-        if (R > 1) {
+        if (sh) {
+            // the interface from one pass over the elements (symbolic.hip, k_iface_mark): the halo lists of the other ranks'
+            // tiles are not there to derive it from
+            magk::RankTiles rt = {};
+            rt.R = R;
+            for (int r_ = 0; r_ <= R; ++r_) rt.lo[r_] = tile_lo(r_);
+            HIPCHK(ctx->iface_mask.reserve((size_t)N + 64));
+            magk::iface_mark(ctx->conn.as<int32_t>(), E, ctx->iperm.as<int32_t>(), N, B, rt, ctx->iface_mask.as<uint8_t>(),
+                             ctx->hcnt.as<int32_t>(), s); // (hcnt / hoffn: free since the halo references were emitted)
+            if (int rc = scan_i32(ctx, ctx->hcnt.as<int32_t>(), ctx->hoffn.as<int32_t>(), (size_t)N + 1)) return rc;
+            int32_t h_ni = 0;
+            HIPCHK(hipMemcpyAsync(&h_ni, ctx->hoffn.as<int32_t>() + N, 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            ctx->n_iface = h_ni;
+            HIPCHK(ctx->iface.reserve(4 * ((size_t)h_ni + 1)));
+            HIPCHK(ctx->iface_readers.reserve((size_t)h_ni + 16));
+            magk::iface_emit(ctx->iface_mask.as<uint8_t>(), ctx->hoffn.as<int32_t>(), N, ctx->iface.as<int32_t>(),
+                             ctx->iface_readers.as<uint8_t>(), s);
+        } else if (R > 1) {
             // interface = every node some rank reads (tile halo) but does not own; every rank derives the same
             // sorted list from the replicated symbolic data, so no communication is needed to agree on it
             std::vector<int32_t> hoff((size_t)T + 1), hg((size_t)std::max<int64_t>(ctx->halo_total, 1));
@@ -438,8 +487,20 @@ int ensure_order(mag_ctx *ctx)
             }
             HIPCHK(hipStreamSynchronize(s)); // the host vectors must outlive the copies
         }
-        HIPCHK(ctx->comm_pq.reserve(64));
+        HIPCHK(ctx->comm_pq.reserve(128));
         HIPCHK(ctx->comm_rr.reserve(8 * (1 + 2 * (size_t)ctx->n_iface) + 64));
+    }
+    if (sh) {
+        // what all ranks must decide alike hangs on the largest halo of ANY tile (the LDS layout, on-chip or streaming): every
+        // rank puts the largest of the tiles it built into its own word of a vector, one sum-all-reduce, the maximum
+        double hv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        hv[me] = (double)max_halo;
+        std::string msg;
+        HIPCHK(hipMemcpyAsync(ctx->comm_pq.p, hv, 64, hipMemcpyHostToDevice, s));
+        if (int rc = ctx->comm.allreduce_sum(ctx->comm_pq.as<double>(), 8, s, msg)) return fail(ctx, rc, "%s", msg.c_str());
+        HIPCHK(hipMemcpyAsync(hv, ctx->comm_pq.p, 64, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (int r_ = 0; r_ < R; ++r_) max_halo = std::max(max_halo, (int32_t)hv[r_]);
     }
     ctx->max_halo = max_halo;
     ctx->cap = ((B + max_halo + 31) / 32) * 32;
@@ -471,6 +532,18 @@ int ensure_order(mag_ctx *ctx)
                         ctx->tile_hoff.as<int32_t>(), T,
                         ctx->tmeta.as<magk::TileMeta>(), s);
         magk::mark_published(ctx->halo_g.as<int32_t>(), ctx->halo_total, ctx->maskP.as<uint8_t>(), s);
+        if (sh) { // the edge-block eligibility of the WHOLE mesh: k_ring16's flag word, OR-ed over the ranks
+            int32_t ff = 3;
+            HIPCHK(hipMemcpyAsync(&ff, ctx->tile_rdeg.as<int32_t>() + 2 * (size_t)T, 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            double fv[2] = {(double)(ff & 1), (double)((ff >> 1) & 1)};
+            std::string msg;
+            HIPCHK(hipMemcpyAsync(ctx->comm_pq.p, fv, 16, hipMemcpyHostToDevice, s));
+            if (int rc = ctx->comm.allreduce_sum(ctx->comm_pq.as<double>(), 2, s, msg)) return fail(ctx, rc, "%s", msg.c_str());
+            HIPCHK(hipMemcpyAsync(fv, ctx->comm_pq.p, 16, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            ctx->fan_flags_global = (fv[0] > 0.0 ? 1 : 0) | (fv[1] > 0.0 ? 2 : 0);
+        }
     } else {
         HIPCHK(ctx->ell.reserve(8 * (size_t)(h_total > 0 ? h_total : 1)));
         magk::fill_ell(ctx->inc_off.as<int32_t>(), ctx->inc.as<uint32_t>(), ctx->conn.as<int32_t>(),
@@ -482,7 +555,6 @@ int ensure_order(mag_ctx *ctx)
     // ranks the decision uses only quantities every rank computes identically (the largest tile count of a rank, the
     // global halo bound, the window size), so all ranks take the same path.
     ctx->persist = false;
-    const int R = ctx->comm.nranks;
     const bool mg = R > 1;
     const bool forced_dist = ctx->dist && !mg; // single-rank rehearsal of the distributed protocol: streaming kernels
     if (ctx->opt.cg_variant == 2 && ctx->use_lds && !forced_dist && !ctx->persist_failed && ctx->opt.precision == 0 &&
@@ -676,12 +748,21 @@ int gather_phase(mag_ctx *ctx)
     return MAG_OK;
 }
 
+// the whole mesh's tables: a run across ranks has left those of the tiles this rank needs only (order_sharded); the entry
+// points that walk the whole mesh on ONE rank (all of K, plain operator applications) rebuild them here -- without the sharded
+// phase's all-reduces, which only mag_run may enter
+int ensure_full_order(mag_ctx *ctx)
+{
+    if (ctx->have_order && ctx->order_sharded) ctx->have_order = ctx->have_csr = false;
+    return ensure_order(ctx);
+}
+
 // all of K, for the entry points that hand K out (mag_assemble_csr, mag_reduce_system): a multi-rank context whose run
 // kept only its own rows builds the whole matrix here
 int ensure_csr(mag_ctx *ctx)
 {
     if (ctx->have_csr && ctx->csr_full) return MAG_OK;
-    if (int rc = ensure_order(ctx)) return rc; // validates conn
+    if (int rc = ensure_full_order(ctx)) return rc; // validates conn
     ctx->want_full_csr = true;
     int rc = csr_symbolic(ctx);
     ctx->want_full_csr = false;
@@ -1345,8 +1426,12 @@ int cg_phase_persist(mag_ctx *ctx)
     const char *mgb = getenv("MAG_TUNE_PERSIST_MG_BLOCKS");
     if ((!mg || !(mgb && atoi(mgb) == 0)) && !getenv("MAG_TUNE_PERSIST_TRIANGLES")) {
         int32_t fan_flags = 3;
-        HIPCHK(hipMemcpyAsync(&fan_flags, ctx->tile_rdeg.as<int32_t>() + 2 * (size_t)ctx->T, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        if (ctx->order_sharded) { // (this rank's ring words cover its own tiles only: the ordering phase has OR-ed the flags over the ranks)
+            fan_flags = ctx->fan_flags_global;
+        } else {
+            HIPCHK(hipMemcpyAsync(&fan_flags, ctx->tile_rdeg.as<int32_t>() + 2 * (size_t)ctx->T, 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+        }
         if (fan_flags == 0) eb_mode = 1;
         const char *no_ovf = getenv("MAG_TUNE_PERSIST_NO_OVERFLOW");
         const char *mgo = getenv("MAG_TUNE_PERSIST_MG_OVERFLOW"); // =0: several ranks keep the triangle walk on such meshes
@@ -1362,7 +1447,9 @@ int cg_phase_persist(mag_ctx *ctx)
             HIPCHK(hipMemsetAsync(lim_d, 0, 8, s));
             // (several ranks: the limits over EVERY rank's workgroups -- the ordering phase is replicated --, so that all ranks
             // reach the same decision)
+            // (sharded ordering phase: only the own tiles' rows are known here -- the ranks vote below)
             for (int r_ = 0; r_ < ctx->comm.nranks; ++r_) {
+                if (ctx->order_sharded && r_ != ctx->comm.rank) continue;
                 const int32_t ta = mg ? (int32_t)(((int64_t)ctx->T * r_) / ctx->comm.nranks) : ctx->t0;
                 const int32_t tb = mg ? (int32_t)(((int64_t)ctx->T * (r_ + 1)) / ctx->comm.nranks) : ctx->t1;
                 magk::ovf_limits(ctx->ovf_off.as<int32_t>(), ctx->B, ctx->persist_k, ta, tb, lim_d, s);
@@ -1373,8 +1460,18 @@ int cg_phase_persist(mag_ctx *ctx)
             HIPCHK(hipStreamSynchronize(s));
             const int32_t pool = ((lim[0] + 1 + 7) / 8) * 8; // + record 0, the zero block
             // 12 bits of pool position and 4 bits of count per node slot; the kernel's static LDS on top of the dynamic
-            if (lim[0] + 1 <= 4095 && lim[1] <= 15 &&
-                magk::persist_lds_bytes(ctx->B, ctx->cap, ctx->persist_maxh, magk::persist_threads(), 2, pool, mg) + 256 <= 160 * 1024) {
+            bool fits = lim[0] + 1 <= 4095 && lim[1] <= 15 &&
+                        magk::persist_lds_bytes(ctx->B, ctx->cap, ctx->persist_maxh, magk::persist_threads(), 2, pool, mg) + 256 <= 160 * 1024;
+            if (ctx->order_sharded) { // one instantiation for all ranks: a rank whose pool does not fit sends everybody to the walk
+                double v = fits ? 0.0 : 1.0;
+                std::string msg;
+                HIPCHK(hipMemcpyAsync(ctx->comm_pq.p, &v, 8, hipMemcpyHostToDevice, s));
+                if (int rc = ctx->comm.allreduce_sum(ctx->comm_pq.as<double>(), 1, s, msg)) return fail(ctx, rc, "%s", msg.c_str());
+                HIPCHK(hipMemcpyAsync(&v, ctx->comm_pq.p, 8, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                fits = v == 0.0;
+            }
+            if (fits) {
                 eb_mode = 2;
                 P.pool_cap = pool;
                 HIPCHK(ctx->ovf_rec.reserve(32 * (size_t)std::max(lim[2], 1)));
@@ -1937,7 +2034,10 @@ int mag_run(mag_ctx *ctx)
     if (ctx->opt.verbose) printf("info: building element stiffness matrices...\n");
 
     HIPCHK(hipEventRecord(ctx->ev[0], s));
-    if (int rc = ensure_order(ctx)) return rc;
+    ctx->order_allow_shard = true; // (every rank of the communicator is in mag_run: the sharded phase's all-reduces are safe)
+    const int rc_order = ensure_order(ctx);
+    ctx->order_allow_shard = false;
+    if (rc_order) return rc_order;
     HIPCHK(hipEventRecord(ctx->ev[1], s));
     if (int rc = reserve_cg(ctx)) return rc;
     const bool csr = ctx->opt.assemble_csr != 0 || ctx->opt.cg_operator == MAG_OP_CSR;
@@ -2188,7 +2288,7 @@ int mag_apply_operator(mag_ctx *ctx, const double *x, double *y, int32_t masked)
     if (int rc = enter(ctx)) return rc;
     if (!ctx->have_problem) return fail(ctx, MAG_ERR_STATE, "no problem uploaded");
     if (!x || !y) return fail(ctx, MAG_ERR_BAD_ARGS, "null vector");
-    if (int rc = ensure_order(ctx)) return rc;
+    if (int rc = ensure_full_order(ctx)) return rc;
     if (int rc = reserve_cg(ctx)) return rc;
     const int64_t N = ctx->N;
     hipStream_t s = ctx->stream;

@@ -39,6 +39,22 @@ void apply_order(const uint32_t *perm, const double *xy, const uint8_t *u_known,
 // per element corner k=3e+c: keys[k] = iperm[conn[k]], vals[k] = k, deg[key]++ ; out-of-range conn sets *err
 void incidence_keys(const int32_t *conn, int64_t E, const int32_t *iperm, int64_t N, uint32_t *keys,
                     uint32_t *vals, int32_t *deg, int32_t *err, hipStream_t s);
+// several ranks, sharded ordering phase (symbolic.hip): tiles whose tables this rank needs; incidence pairs of their nodes only;
+// the interface list and its reader masks from one pass over the elements
+struct RankTiles {
+    int32_t lo[9]; // first tile of rank r (lo[R] = T)
+    int32_t R;
+};
+void need_tiles(const int32_t *conn, int64_t E, const int32_t *iperm, const uint8_t *maskP, int64_t N, int32_t B, int32_t T,
+                int32_t t0, int32_t t1, bool prescribed_rows, uint8_t *need, hipStream_t s);
+void incidence_flags(const int32_t *conn, int64_t E, const int32_t *iperm, int64_t N, int32_t B, const uint8_t *need,
+                     int32_t *flag, int32_t *err, hipStream_t s);
+void incidence_emit(const int32_t *conn, int64_t E, const int32_t *iperm, int64_t N, const int32_t *off, uint32_t *keys,
+                    uint32_t *vals, int32_t *deg, hipStream_t s);
+void zero_unneeded_deg(const uint8_t *need, int64_t N, int32_t B, int32_t *deg, hipStream_t s);
+void iface_mark(const int32_t *conn, int64_t E, const int32_t *iperm, int64_t N, int32_t B, const RankTiles &rt,
+                uint8_t *readers, int32_t *flag, hipStream_t s);
+void iface_emit(const uint8_t *readers, const int32_t *off, int64_t N, int32_t *iface, uint8_t *iface_readers, hipStream_t s);
 // tile_deg[t] = max deg over the tile's nodes; tile_cnt[t] = tile_deg[t] * B  (int64)
 void tile_degree(const int32_t *deg, int64_t N, int32_t B, int32_t T, int32_t *tile_deg, int64_t *tile_cnt,
                  hipStream_t s);

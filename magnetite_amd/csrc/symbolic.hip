@@ -423,6 +423,7 @@ __global__ void __launch_bounds__(256) k_fill_ell16(const int32_t *inc_off, cons
 {
     const int32_t t = blockIdx.x;
     const int32_t td = tile_deg[t];
+    if (td == 0) return; // no triangle at any node of the tile (sharded ordering phase: a tile this rank does not need)
     const int32_t base = t * B;
     const int32_t *hl = halo_g + tile_hoff[t];
     const int32_t nh = tile_hoff[t + 1] - tile_hoff[t];
@@ -554,6 +555,7 @@ __global__ void __launch_bounds__(256) k_ring16(const int32_t *tile_deg, const i
 {
     const int32_t t = blockIdx.x;
     const int32_t td = tile_deg[t];
+    if (td == 0) return; // an empty tile: row_info stays at the launcher's 0x80 ("one fan, no entries") for all of its rows
     uint32_t *dst = ell + tile_off[t];
     int32_t wmax = 0, emax = 0;
     // Is every row ONE fan of at most nb entries, or nb + 1 with the last entry closing onto the first?  Then the on-chip CG
@@ -667,6 +669,7 @@ void ring16(const int32_t *tile_deg, const int64_t *tile_off, int32_t B, int32_t
     // [0, T): words, [T, 2T): entries of the longest row, [2T]: bit 0 some row is not a plain short fan, bit 1 some row is
     // not one fan (see k_ring16)
     (void)hipMemsetAsync(tile_rdeg, 0, 4 * (2 * (size_t)T + 1), s);
+    if (row_info) (void)hipMemsetAsync(row_info, 0x80, (size_t)T * (size_t)B, s);
     k_ring16<<<T, 256, 0, s>>>(tile_deg, tile_off, B, ell, tile_rdeg, block_entries, row_info);
 }
 
@@ -713,6 +716,168 @@ void ovf_limits(const int32_t *off, int32_t B, int32_t k, int32_t t0, int32_t t1
 {
     const int32_t grid = (t1 - t0 + k - 1) / k;
     if (grid > 0) k_ovf_limits<<<grid, 256, 0, s>>>(off, B, k, t0, t1, out);
+}
+
+// ------------------------------------------- sharded ordering phase (several ranks) ---
+// The node ORDER is global (every rank must agree on every node's index); everything derived from it -- incidence lists,
+// halo lists, ELL / ring words, tile tables -- a rank needs only for the tiles that hold a row it keeps: its own tiles, the tiles
+// of its ghost nodes (nodes that share an element with an own node: their rows give the right-hand side of the ghost
+// recurrences) and the tiles of the prescribed nodes (their rows give the reactions).  need[t] marks those tiles; nodes of
+// other tiles get empty incidence lists, so every later kernel finds nothing to do there.
+__global__ void __launch_bounds__(256) k_need_tiles_elems(const int32_t *conn, int64_t E, const int32_t *iperm, int64_t N,
+                                                          int32_t B, int32_t t0, int32_t t1, uint8_t *need)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    int32_t t[3];
+    bool own = false;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int32_t n = conn[3 * e + c];
+        if (n < 0 || (int64_t)n >= N) n = 0; // (reported by the incidence kernel)
+        t[c] = iperm[n] / B;
+        own = own || (t[c] >= t0 && t[c] < t1);
+    }
+    if (own) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) need[t[c]] = 1;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_need_tiles_nodes(const uint8_t *maskP, int64_t N, int32_t B, uint8_t *need)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g < N && (maskP[g] & 3)) need[g / B] = 1;
+}
+
+void need_tiles(const int32_t *conn, int64_t E, const int32_t *iperm, const uint8_t *maskP, int64_t N, int32_t B, int32_t T,
+                int32_t t0, int32_t t1, bool prescribed_rows, uint8_t *need, hipStream_t s)
+{
+    (void)hipMemsetAsync(need, 0, (size_t)T, s);
+    if (t1 > t0) (void)hipMemsetAsync(need + t0, 1, (size_t)(t1 - t0), s);
+    k_need_tiles_elems<<<blocks_for(E, 256), 256, 0, s>>>(conn, E, iperm, N, B, t0, t1, need);
+    if (prescribed_rows) k_need_tiles_nodes<<<blocks_for(N, 256), 256, 0, s>>>(maskP, N, B, need);
+}
+
+// incidence pairs of the needed tiles' nodes only: flag, scan (caller), emit in the order of k -- the stable sort by node then
+// leaves every node's elements ascending, exactly as the unsharded list has them
+__global__ void __launch_bounds__(256) k_incidence_flags(const int32_t *conn, int64_t n3, const int32_t *iperm, int64_t N,
+                                                         int32_t B, const uint8_t *need, int32_t *flag, int32_t *err)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k > n3) return;
+    int32_t f = 0;
+    if (k < n3) {
+        int32_t n = conn[k];
+        if (n < 0 || (int64_t)n >= N) {
+            atomicOr(err, 1);
+            n = 0;
+        }
+        f = need[iperm[n] / B] ? 1 : 0;
+    }
+    flag[k] = f; // (flag[n3] = 0: the scan's total lands there)
+}
+
+__global__ void __launch_bounds__(256) k_incidence_emit(const int32_t *conn, int64_t n3, const int32_t *iperm, int64_t N,
+                                                        const int32_t *off, uint32_t *keys, uint32_t *vals, int32_t *deg)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n3) return;
+    const int32_t o = off[k];
+    if (off[k + 1] == o) return;
+    int32_t n = conn[k];
+    if (n < 0 || (int64_t)n >= N) n = 0;
+    const int32_t g = iperm[n];
+    keys[o] = (uint32_t)g;
+    vals[o] = (uint32_t)k;
+    if (deg) atomicAdd(&deg[g], 1);
+}
+
+void incidence_flags(const int32_t *conn, int64_t E, const int32_t *iperm, int64_t N, int32_t B, const uint8_t *need,
+                     int32_t *flag, int32_t *err, hipStream_t s)
+{
+    k_incidence_flags<<<blocks_for(3 * E + 1, 256), 256, 0, s>>>(conn, 3 * E, iperm, N, B, need, flag, err);
+}
+
+void incidence_emit(const int32_t *conn, int64_t E, const int32_t *iperm, int64_t N, const int32_t *off, uint32_t *keys,
+                    uint32_t *vals, int32_t *deg, hipStream_t s)
+{
+    k_incidence_emit<<<blocks_for(3 * E, 256), 256, 0, s>>>(conn, 3 * E, iperm, N, off, keys, vals, deg);
+}
+
+__global__ void __launch_bounds__(256) k_zero_unneeded_deg(const uint8_t *need, int64_t N, int32_t B, int32_t *deg)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g < N && !need[g / B]) deg[g] = 0;
+}
+
+void zero_unneeded_deg(const uint8_t *need, int64_t N, int32_t B, int32_t *deg, hipStream_t s)
+{
+    k_zero_unneeded_deg<<<blocks_for(N, 256), 256, 0, s>>>(need, N, B, deg);
+}
+
+// The interface without any tile table: a node is read by rank r when it shares an element with a node rank r owns (that is
+// what being in the halo of one of r's tiles means).  One pass over the elements ORs the other corners' owners into a byte
+// per node; the interface list is the compaction of the marked nodes in Hilbert order -- the same sorted list and the same
+// reader masks every rank used to derive from the replicated halo lists.
+__device__ inline int rank_of_tile(const RankTiles &rt, int32_t t)
+{
+    int r = 0;
+    while (r + 1 < rt.R && t >= rt.lo[r + 1]) ++r;
+    return r;
+}
+
+__global__ void __launch_bounds__(256) k_iface_mark(const int32_t *conn, int64_t E, const int32_t *iperm, int64_t N, int32_t B,
+                                                    RankTiles rt, uint32_t *readers)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    int32_t g[3];
+    int o[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int32_t n = conn[3 * e + c];
+        if (n < 0 || (int64_t)n >= N) n = 0;
+        g[c] = iperm[n];
+        o[c] = rank_of_tile(rt, g[c] / B);
+    }
+    if (o[0] == o[1] && o[1] == o[2]) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (o[d] != o[c]) m |= 1u << (o[d] & 7);
+        if (m) atomicOr(&readers[g[c] >> 2], m << (8 * (g[c] & 3)));
+    }
+}
+
+__global__ void __launch_bounds__(256) k_iface_flags(const uint8_t *readers, int64_t N, int32_t *flag)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g <= N) flag[g] = g < N && readers[g] ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) k_iface_emit(const uint8_t *readers, const int32_t *off, int64_t N, int32_t *iface,
+                                                    uint8_t *iface_readers)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= N || !readers[g]) return;
+    iface[off[g]] = (int32_t)g;
+    iface_readers[off[g]] = readers[g];
+}
+
+void iface_mark(const int32_t *conn, int64_t E, const int32_t *iperm, int64_t N, int32_t B, const RankTiles &rt,
+                uint8_t *readers, int32_t *flag, hipStream_t s)
+{
+    (void)hipMemsetAsync(readers, 0, (((size_t)N + 3) / 4) * 4, s);
+    k_iface_mark<<<blocks_for(E, 256), 256, 0, s>>>(conn, E, iperm, N, B, rt, (uint32_t *)readers);
+    k_iface_flags<<<blocks_for(N + 1, 256), 256, 0, s>>>(readers, N, flag);
+}
+
+void iface_emit(const uint8_t *readers, const int32_t *off, int64_t N, int32_t *iface, uint8_t *iface_readers, hipStream_t s)
+{
+    k_iface_emit<<<blocks_for(N, 256), 256, 0, s>>>(readers, off, N, iface, iface_readers);
 }
 
 // --------------------------------------------------------- CSR pattern ---
