@@ -197,6 +197,30 @@ def test_eight_ranks_on_chip_edge_blocks_with_overflow_on_an_unstructured_mesh(b
             assert np.array_equal(outs[0]["u"], results[0][0]["u"])
 
 
+def test_eight_ranks_sharded_ordering_phase_builds_the_same_solve(case, monkeypatch):
+    """Across ranks the ordering phase builds incidence lists, halo lists, ring words and tile tables for the tiles a rank
+    needs only -- its own, those of its ghost rows and of the prescribed rows -- and derives the interface from one pass over
+    the elements (round 4; MAG_TUNE_SHARD_ORDER=0: every rank builds the whole mesh's tables, as before).  The tables of
+    a rank's own tiles, the interface list and the decisions the ranks share are the same either way, so both modes return
+    the same bits, on-chip and streaming; the stats show the smaller tables."""
+    p = case[0]
+    for variant in (2, 1):
+        sharded = run_ranks(p, inboxes=True, cg_variant=variant, tile_nodes=512)
+        monkeypatch.setenv("MAG_TUNE_SHARD_ORDER", "0")
+        replicated = run_ranks(p, inboxes=True, cg_variant=variant, tile_nodes=512)
+        monkeypatch.delenv("MAG_TUNE_SHARD_ORDER")
+        check(case, sharded, kernel=variant, exchange=2 if variant == 2 else 3)
+        for (a,), (b,) in zip(sharded, replicated):
+            assert a["cg_kernel"] == b["cg_kernel"] == variant and a["edge_blocks"] == b["edge_blocks"]
+            assert a["iterations"] == b["iterations"] and a["nnz"] == b["nnz"]
+            assert np.array_equal(a["u"], b["u"]) and np.array_equal(a["f"], b["f"]) and np.array_equal(a["stress"], b["stress"])
+            assert a["max_tile_halo"] == b["max_tile_halo"]  # (the largest halo of ANY tile: all-reduced in the sharded phase)
+            assert a["ell_entries"] < b["ell_entries"] and a["halo_nodes"] < b["halo_nodes"]
+        # (the stacked plates are prescribed along both long edges, so every rank needs the tiles along them: about half of
+        # the mesh here; on BASELINE config 5's square a rank builds 15 % of the tables, scripts/order_phase_ranks.py)
+        assert sum(a["ell_entries"] for (a,) in sharded) < 0.7 * sum(b["ell_entries"] for (b,) in replicated)
+
+
 def test_eight_ranks_agree_to_fall_back(case, monkeypatch):
     """MAG_TUNE_PERSIST_SPIN=0: every wait of the on-chip kernels gives up at once; the ranks agree on it through one
     all-reduce of their failure flags and all redo the solve with the streaming kernels -- and say so in their stats"""

@@ -19,4 +19,4 @@ def test_eight_ranks_as_threads_of_one_process(built):
                         "gpu", "-q", "-x", "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True,
                        timeout=1100)
     assert r.returncode == 0, r.stdout[-6000:] + r.stderr[-2000:]
-    assert "12 passed" in r.stdout, r.stdout[-2000:]
+    assert "13 passed" in r.stdout, r.stdout[-2000:]
