@@ -342,8 +342,12 @@ int ensure_order(mag_ctx *ctx)
     if (!counted) HIPCHK(hipMemsetAsync(ctx->deg.p, 0, 4 * ((size_t)N + 1), s));
     if (sh) {
         HIPCHK(ctx->need_tile.reserve((size_t)T + 64));
+        magk::RankTiles rt = {};
+        rt.R = R;
+        for (int r_ = 0; r_ <= R; ++r_) rt.lo[r_] = tile_lo(r_);
+        HIPCHK(ctx->iface_mask.reserve((size_t)N + 64));
         magk::need_tiles(ctx->conn.as<int32_t>(), E, ctx->iperm.as<int32_t>(), ctx->maskP.as<uint8_t>(), N, B, T, ctx->t0, ctx->t1,
-                         true, ctx->need_tile.as<uint8_t>(), s);
+                         true, ctx->need_tile.as<uint8_t>(), rt, ctx->iface_mask.as<uint8_t>(), s);
         if (counted) magk::zero_unneeded_deg(ctx->need_tile.as<uint8_t>(), N, B, ctx->deg.as<int32_t>(), s);
         magk::incidence_flags(ctx->conn.as<int32_t>(), E, ctx->iperm.as<int32_t>(), N, B, ctx->need_tile.as<uint8_t>(),
                               ctx->sK1.as<int32_t>(), errflag, s);
@@ -435,12 +439,8 @@ int ensure_order(mag_ctx *ctx)
         if (sh) {
             // the interface from one pass over the elements (symbolic.hip, k_iface_mark): the halo lists of the other ranks'
             // tiles are not there to derive it from
-            magk::RankTiles rt = {};
-            rt.R = R;
-            for (int r_ = 0; r_ <= R; ++r_) rt.lo[r_] = tile_lo(r_);
-            HIPCHK(ctx->iface_mask.reserve((size_t)N + 64));
-            magk::iface_mark(ctx->conn.as<int32_t>(), E, ctx->iperm.as<int32_t>(), N, B, rt, ctx->iface_mask.as<uint8_t>(),
-                             ctx->hcnt.as<int32_t>(), s); // (hcnt / hoffn: free since the halo references were emitted)
+            // (marked by the pass that found the needed tiles; hcnt / hoffn: free since the halo references were emitted)
+            magk::iface_flags(ctx->iface_mask.as<uint8_t>(), N, ctx->hcnt.as<int32_t>(), s);
             if (int rc = scan_i32(ctx, ctx->hcnt.as<int32_t>(), ctx->hoffn.as<int32_t>(), (size_t)N + 1)) return rc;
             int32_t h_ni = 0;
             HIPCHK(hipMemcpyAsync(&h_ni, ctx->hoffn.as<int32_t>() + N, 4, hipMemcpyDeviceToHost, s));
@@ -630,8 +630,9 @@ int csr_symbolic(mag_ctx *ctx)
         int32_t *ovf = (int32_t *)(ctx->small.as<double>() + 4 * 256 + 4) + 2;
         const uint8_t *local = shard ? ctx->local_node.as<uint8_t>() : nullptr;
         HIPCHK(hipMemsetAsync(ovf, 0, 4, s));
+        const uint8_t *need = shard && ctx->order_sharded ? ctx->need_tile.as<uint8_t>() : nullptr;
         magk::pattern_count(ctx->inc_off.as<int32_t>(), ctx->inc.as<uint32_t>(), ctx->perm.as<uint32_t>(),
-                            ctx->conn.as<int32_t>(), local, N, ctx->rowcnt.as<int32_t>(), ovf, s);
+                            ctx->conn.as<int32_t>(), local, N, ctx->rowcnt.as<int32_t>(), ovf, need, ctx->B, s);
         if (int rc = scan_i32(ctx, ctx->rowcnt.as<int32_t>(), ctx->bptr.as<int32_t>(), (size_t)N + 1)) return rc;
         int32_t h_nb = 0, h_ovf = 0;
         HIPCHK(hipMemcpyAsync(&h_nb, ctx->bptr.as<int32_t>() + N, 4, hipMemcpyDeviceToHost, s));
@@ -648,7 +649,7 @@ int csr_symbolic(mag_ctx *ctx)
             HIPCHK(ctx->bc_touch.reserve((size_t)N + 16));
             magk::pattern_fill(ctx->inc_off.as<int32_t>(), ctx->inc.as<uint32_t>(), ctx->perm.as<uint32_t>(),
                                ctx->conn.as<int32_t>(), local, N, ctx->bptr.as<int32_t>(), ctx->bcol.as<int32_t>(),
-                               ctx->uknown.as<uint8_t>(), ctx->bc_touch.as<uint8_t>(), s);
+                               ctx->uknown.as<uint8_t>(), ctx->bc_touch.as<uint8_t>(), need, ctx->B, s);
             ctx->bc_touch_ready = true;
             HIPCHK(hipGetLastError());
             return MAG_OK;

@@ -46,14 +46,13 @@ struct RankTiles {
     int32_t R;
 };
 void need_tiles(const int32_t *conn, int64_t E, const int32_t *iperm, const uint8_t *maskP, int64_t N, int32_t B, int32_t T,
-                int32_t t0, int32_t t1, bool prescribed_rows, uint8_t *need, hipStream_t s);
+                int32_t t0, int32_t t1, bool prescribed_rows, uint8_t *need, const RankTiles &rt, uint8_t *readers, hipStream_t s);
 void incidence_flags(const int32_t *conn, int64_t E, const int32_t *iperm, int64_t N, int32_t B, const uint8_t *need,
                      int32_t *flag, int32_t *err, hipStream_t s);
 void incidence_emit(const int32_t *conn, int64_t E, const int32_t *iperm, int64_t N, const int32_t *off, uint32_t *keys,
                     uint32_t *vals, int32_t *deg, hipStream_t s);
 void zero_unneeded_deg(const uint8_t *need, int64_t N, int32_t B, int32_t *deg, hipStream_t s);
-void iface_mark(const int32_t *conn, int64_t E, const int32_t *iperm, int64_t N, int32_t B, const RankTiles &rt,
-                uint8_t *readers, int32_t *flag, hipStream_t s);
+void iface_flags(const uint8_t *readers, int64_t N, int32_t *flag, hipStream_t s);
 void iface_emit(const uint8_t *readers, const int32_t *off, int64_t N, int32_t *iface, uint8_t *iface_readers, hipStream_t s);
 // tile_deg[t] = max deg over the tile's nodes; tile_cnt[t] = tile_deg[t] * B  (int64)
 void tile_degree(const int32_t *deg, int64_t N, int32_t B, int32_t T, int32_t *tile_deg, int64_t *tile_cnt,
@@ -90,10 +89,11 @@ void csr_pairs(const int32_t *conn, int64_t E, uint64_t *keys, uint32_t *vals, h
 // local is given and local[i] == 0; rowcnt[N] = 0), *overflow = 1 if a row exceeds the register array; then, with
 // bptr = scan(rowcnt), bcol[bptr[i] ..] = those nodes, ascending
 void pattern_count(const int32_t *inc_off, const uint32_t *inc, const uint32_t *perm, const int32_t *conn,
-                   const uint8_t *local, int64_t N, int32_t *rowcnt, int32_t *overflow, hipStream_t s);
+                   const uint8_t *local, int64_t N, int32_t *rowcnt, int32_t *overflow, const uint8_t *need, int32_t B,
+                   hipStream_t s);
 void pattern_fill(const int32_t *inc_off, const uint32_t *inc, const uint32_t *perm, const int32_t *conn,
                   const uint8_t *local, int64_t N, const int32_t *bptr, int32_t *bcol, const uint8_t *u_known,
-                  uint8_t *touch, hipStream_t s);
+                  uint8_t *touch, const uint8_t *need, int32_t B, hipStream_t s);
 // multi-GPU: local[i] = 1 for the nodes whose K rows this rank keeps (owned, one ghost layer, prescribed nodes) ...
 void mark_local(const uint32_t *perm, const uint8_t *maskP, int64_t N, int32_t own0, int32_t own1,
                 const int32_t *halo_g, int32_t h0, int32_t h1, uint8_t *local, hipStream_t s);

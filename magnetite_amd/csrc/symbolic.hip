@@ -178,12 +178,64 @@ void apply_order(const uint32_t *perm, const double *xy, const uint8_t *u_known,
 // rotated by a tile-dependent quarter (below), so that the long rows of a workgroup's four tiles fall on different waves.  A tile
 // whose nodes all have class 0 -- every tile of a structured mesh -- keeps its order: the permutation is the identity there.
 // cdeg: triangles per node in CALLER numbering (k_count_degree).  One workgroup of B threads per tile.
+// (A block takes 4096 consecutive elements.  When their node ids lie within kCountBins of each other -- meshes whose elements
+// and nodes are numbered along the geometry, as mesh generators leave them -- the block counts in LDS and adds every node's
+// count to memory once: a third to a sixth of the atomics; otherwise one atomic per corner, as before.)
+constexpr int kCountPer = 48, kCountBins = 12288;
 __global__ void __launch_bounds__(256) k_count_degree(const int32_t *conn, int64_t n3, int64_t N, int32_t *cdeg)
 {
-    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (k >= n3) return;
-    const int32_t n = conn[k];
-    if (n >= 0 && (int64_t)n < N) atomicAdd(&cdeg[n], 1); // (an index out of range is reported by k_incidence_keys)
+    __shared__ int32_t s_lo, s_hi;
+    __shared__ uint32_t s_h[kCountBins];
+    const int64_t base = (int64_t)blockIdx.x * 256 * kCountPer;
+    if (threadIdx.x == 0) {
+        s_lo = 0x7fffffff;
+        s_hi = -1;
+    }
+    __syncthreads();
+    int32_t lo = 0x7fffffff, hi = -1;
+    for (int j = 0; j < kCountPer; ++j) {
+        const int64_t k = base + (int64_t)j * 256 + threadIdx.x;
+        if (k >= n3) break;
+        const int32_t n = conn[k];
+        if (n >= 0 && (int64_t)n < N) { // (an index out of range is reported by the incidence kernel)
+            lo = n < lo ? n : lo;
+            hi = n > hi ? n : hi;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, __shfl_xor(lo, off));
+        hi = max(hi, __shfl_xor(hi, off));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&s_lo, lo);
+        atomicMax(&s_hi, hi);
+    }
+    __syncthreads();
+    lo = s_lo;
+    hi = s_hi;
+    if (hi < lo) return;
+    const int32_t range = hi - lo + 1;
+    const bool local = range <= kCountBins;
+    if (local) {
+        for (int b = threadIdx.x; b < range; b += 256) s_h[b] = 0;
+        __syncthreads();
+    }
+    for (int j = 0; j < kCountPer; ++j) {
+        const int64_t k = base + (int64_t)j * 256 + threadIdx.x;
+        if (k >= n3) break;
+        const int32_t n = conn[k];
+        if (n < 0 || (int64_t)n >= N) continue;
+        if (local)
+            atomicAdd(&s_h[n - lo], 1u);
+        else
+            atomicAdd(&cdeg[n], 1);
+    }
+    if (!local) return;
+    __syncthreads();
+    for (int b = threadIdx.x; b < range; b += 256) {
+        const uint32_t c = s_h[b];
+        if (c) atomicAdd(&cdeg[lo + b], (int32_t)c);
+    }
 }
 
 template <int B>
@@ -227,7 +279,7 @@ __global__ void __launch_bounds__(B) k_tile_valence_partition(const uint32_t *pe
 
 void count_degree(const int32_t *conn, int64_t E, int64_t N, int32_t *cdeg, hipStream_t s)
 {
-    k_count_degree<<<blocks_for(3 * E, 256), 256, 0, s>>>(conn, 3 * E, N, cdeg);
+    k_count_degree<<<blocks_for(3 * E, 256 * kCountPer), 256, 0, s>>>(conn, 3 * E, N, cdeg);
 }
 
 void tile_valence_partition(const uint32_t *perm_in, const int32_t *cdeg, int64_t N, int32_t B, int32_t T, uint32_t *perm_out,
@@ -724,23 +776,48 @@ void ovf_limits(const int32_t *off, int32_t B, int32_t k, int32_t t0, int32_t t1
 // of its ghost nodes (nodes that share an element with an own node: their rows give the right-hand side of the ghost
 // recurrences) and the tiles of the prescribed nodes (their rows give the reactions).  need[t] marks those tiles; nodes of
 // other tiles get empty incidence lists, so every later kernel finds nothing to do there.
+// (the same pass marks the interface: see k_iface_flags below)
+__device__ inline int rank_of_tile(const RankTiles &rt, int32_t t)
+{
+    int r = 0;
+    while (r + 1 < rt.R && t >= rt.lo[r + 1]) ++r;
+    return r;
+}
+
 __global__ void __launch_bounds__(256) k_need_tiles_elems(const int32_t *conn, int64_t E, const int32_t *iperm, int64_t N,
-                                                          int32_t B, int32_t t0, int32_t t1, uint8_t *need)
+                                                          int32_t B, int32_t t0, int32_t t1, uint8_t *need, RankTiles rt,
+                                                          uint32_t *readers)
 {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= E) return;
-    int32_t t[3];
+    int32_t g[3], t[3];
     bool own = false;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         int32_t n = conn[3 * e + c];
         if (n < 0 || (int64_t)n >= N) n = 0; // (reported by the incidence kernel)
-        t[c] = iperm[n] / B;
+        g[c] = iperm[n];
+        t[c] = g[c] / B;
         own = own || (t[c] >= t0 && t[c] < t1);
     }
     if (own) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) need[t[c]] = 1;
+    }
+    // The interface without any tile table: a node is read by rank r when it shares an element with a node rank r owns (that
+    // is what being in the halo of one of r's tiles means): the other corners' owners are OR-ed into a byte per node.
+    if (t[0] == t[1] && t[1] == t[2]) return;
+    int o[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = rank_of_tile(rt, t[c]);
+    if (o[0] == o[1] && o[1] == o[2]) return;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            if (o[d] != o[c]) m |= 1u << (o[d] & 7);
+        if (m) atomicOr(&readers[g[c] >> 2], m << (8 * (g[c] & 3)));
     }
 }
 
@@ -751,11 +828,12 @@ __global__ void __launch_bounds__(256) k_need_tiles_nodes(const uint8_t *maskP, 
 }
 
 void need_tiles(const int32_t *conn, int64_t E, const int32_t *iperm, const uint8_t *maskP, int64_t N, int32_t B, int32_t T,
-                int32_t t0, int32_t t1, bool prescribed_rows, uint8_t *need, hipStream_t s)
+                int32_t t0, int32_t t1, bool prescribed_rows, uint8_t *need, const RankTiles &rt, uint8_t *readers, hipStream_t s)
 {
     (void)hipMemsetAsync(need, 0, (size_t)T, s);
     if (t1 > t0) (void)hipMemsetAsync(need + t0, 1, (size_t)(t1 - t0), s);
-    k_need_tiles_elems<<<blocks_for(E, 256), 256, 0, s>>>(conn, E, iperm, N, B, t0, t1, need);
+    (void)hipMemsetAsync(readers, 0, (((size_t)N + 3) / 4) * 4, s);
+    k_need_tiles_elems<<<blocks_for(E, 256), 256, 0, s>>>(conn, E, iperm, N, B, t0, t1, need, rt, (uint32_t *)readers);
     if (prescribed_rows) k_need_tiles_nodes<<<blocks_for(N, 256), 256, 0, s>>>(maskP, N, B, need);
 }
 
@@ -816,42 +894,8 @@ void zero_unneeded_deg(const uint8_t *need, int64_t N, int32_t B, int32_t *deg, 
     k_zero_unneeded_deg<<<blocks_for(N, 256), 256, 0, s>>>(need, N, B, deg);
 }
 
-// The interface without any tile table: a node is read by rank r when it shares an element with a node rank r owns (that is
-// what being in the halo of one of r's tiles means).  One pass over the elements ORs the other corners' owners into a byte
-// per node; the interface list is the compaction of the marked nodes in Hilbert order -- the same sorted list and the same
-// reader masks every rank used to derive from the replicated halo lists.
-__device__ inline int rank_of_tile(const RankTiles &rt, int32_t t)
-{
-    int r = 0;
-    while (r + 1 < rt.R && t >= rt.lo[r + 1]) ++r;
-    return r;
-}
-
-__global__ void __launch_bounds__(256) k_iface_mark(const int32_t *conn, int64_t E, const int32_t *iperm, int64_t N, int32_t B,
-                                                    RankTiles rt, uint32_t *readers)
-{
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= E) return;
-    int32_t g[3];
-    int o[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        int32_t n = conn[3 * e + c];
-        if (n < 0 || (int64_t)n >= N) n = 0;
-        g[c] = iperm[n];
-        o[c] = rank_of_tile(rt, g[c] / B);
-    }
-    if (o[0] == o[1] && o[1] == o[2]) return;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        uint32_t m = 0;
-#pragma unroll
-        for (int d = 0; d < 3; ++d)
-            if (o[d] != o[c]) m |= 1u << (o[d] & 7);
-        if (m) atomicOr(&readers[g[c] >> 2], m << (8 * (g[c] & 3)));
-    }
-}
-
+// the interface list: the compaction, in Hilbert order, of the nodes k_need_tiles_elems has marked -- the same sorted list and the
+// same reader masks every rank used to derive from the replicated halo lists
 __global__ void __launch_bounds__(256) k_iface_flags(const uint8_t *readers, int64_t N, int32_t *flag)
 {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -867,11 +911,8 @@ __global__ void __launch_bounds__(256) k_iface_emit(const uint8_t *readers, cons
     iface_readers[off[g]] = readers[g];
 }
 
-void iface_mark(const int32_t *conn, int64_t E, const int32_t *iperm, int64_t N, int32_t B, const RankTiles &rt,
-                uint8_t *readers, int32_t *flag, hipStream_t s)
+void iface_flags(const uint8_t *readers, int64_t N, int32_t *flag, hipStream_t s)
 {
-    (void)hipMemsetAsync(readers, 0, (((size_t)N + 3) / 4) * 4, s);
-    k_iface_mark<<<blocks_for(E, 256), 256, 0, s>>>(conn, E, iperm, N, B, rt, (uint32_t *)readers);
     k_iface_flags<<<blocks_for(N + 1, 256), 256, 0, s>>>(readers, N, flag);
 }
 
@@ -911,12 +952,16 @@ template <bool FILL>
 __global__ void __launch_bounds__(256) k_pattern_rows(const int32_t *inc_off, const uint32_t *inc, const uint32_t *perm,
                                                       const int32_t *conn, const uint8_t *local, int64_t N,
                                                       const int32_t *bptr, int32_t *out, int32_t *overflow,
-                                                      const uint8_t *u_known, uint8_t *touch)
+                                                      const uint8_t *u_known, uint8_t *touch, const uint8_t *need, int32_t B)
 {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (g > N) return;
     if (g == N) {
         if (!FILL) out[N] = 0; // sentinel for the exclusive scan
+        return;
+    }
+    if (need && !need[g / B]) { // sharded ordering phase: no row of this tile is kept (the counts were zeroed by the launcher)
+        if (FILL && touch) touch[g] = 0;
         return;
     }
     const int64_t i = perm[g];
@@ -987,19 +1032,21 @@ __global__ void __launch_bounds__(256) k_pattern_rows(const int32_t *inc_off, co
 }
 
 void pattern_count(const int32_t *inc_off, const uint32_t *inc, const uint32_t *perm, const int32_t *conn,
-                   const uint8_t *local, int64_t N, int32_t *rowcnt, int32_t *overflow, hipStream_t s)
+                   const uint8_t *local, int64_t N, int32_t *rowcnt, int32_t *overflow, const uint8_t *need, int32_t B,
+                   hipStream_t s)
 {
+    if (need) (void)hipMemsetAsync(rowcnt, 0, 4 * ((size_t)N + 1), s);
     k_pattern_rows<false><<<blocks_for(N + 1, 256), 256, 0, s>>>(inc_off, inc, perm, conn, local, N, nullptr, rowcnt,
-                                                                overflow, nullptr, nullptr);
+                                                                overflow, nullptr, nullptr, need, B);
 }
 
 // touch (N bytes, may be null): 1 for the rows with a prescribed column (u_known: 2N bytes, caller numbering)
 void pattern_fill(const int32_t *inc_off, const uint32_t *inc, const uint32_t *perm, const int32_t *conn,
                   const uint8_t *local, int64_t N, const int32_t *bptr, int32_t *bcol, const uint8_t *u_known,
-                  uint8_t *touch, hipStream_t s)
+                  uint8_t *touch, const uint8_t *need, int32_t B, hipStream_t s)
 {
     k_pattern_rows<true><<<blocks_for(N + 1, 256), 256, 0, s>>>(inc_off, inc, perm, conn, local, N, bptr, bcol, nullptr,
-                                                               u_known, touch);
+                                                               u_known, touch, need, B);
 }
 
 // ---- multi-GPU: the pattern of the rows a rank keeps (owned nodes, one ghost layer, prescribed nodes) ----
