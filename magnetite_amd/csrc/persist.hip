@@ -1846,9 +1846,10 @@ template <int B>
 __global__ void __launch_bounds__(256) k_edge_blocks(const PersistParams P, double *kbg)
 {
     constexpr int NB = kPersistBlockEntries, NW = (NB + 2) / 2;
-    const int64_t nd = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // (several ranks: the blocks of this rank's own tiles only -- the launcher's grid covers [t0, t1))
+    const int64_t nd = (P.nranks > 1 ? (int64_t)P.t0 * B : 0) + (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int32_t t = (int32_t)(nd / B), lt = (int32_t)(nd % B);
-    if (t >= P.T) return;
+    if (t >= (P.nranks > 1 ? P.t1 : P.T)) return;
     const TileMeta tm = P.meta[t];
     double kb[3 * NB];
 #pragma unroll
@@ -1881,9 +1882,9 @@ template <int B>
 __global__ void __launch_bounds__(256) k_edge_blocks_ovf(const PersistParams P, double *kbg)
 {
     constexpr int NB = kPersistBlockEntries;
-    const int64_t nd = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t nd = (P.nranks > 1 ? (int64_t)P.t0 * B : 0) + (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int32_t t = (int32_t)(nd / B), lt = (int32_t)(nd % B);
-    if (t >= P.T) return;
+    if (t >= (P.nranks > 1 ? P.t1 : P.T)) return;
     const TileMeta tm = P.meta[t];
     const uint32_t info = nd < P.N ? P.row_info[nd] : 0u;
     const int32_t n = (info & 0x80u) ? (int32_t)(info & 63u) : 0;
@@ -1970,7 +1971,7 @@ __global__ void __launch_bounds__(256) k_edge_blocks_ovf(const PersistParams P, 
 
 void edge_blocks_build(const PersistParams &P, int32_t B, double *kblocks, int eb_mode, hipStream_t s)
 {
-    const int64_t npad = (int64_t)P.T * B;
+    const int64_t npad = (int64_t)(P.nranks > 1 ? P.t1 - P.t0 : P.T) * B; // several ranks: this rank's own tiles
     const unsigned blocks = (unsigned)((npad + 255) / 256);
     if (eb_mode == 2) {
         if (B == 256)
