@@ -330,7 +330,8 @@ int ensure_order(mag_ctx *ctx)
     auto tile_lo = [&](int s_) { return (int32_t)(((int64_t)T * s_) / R); };
     ctx->t0 = tile_lo(me);
     ctx->t1 = tile_lo(me + 1);
-    if (R > 1 && ctx->t1 <= ctx->t0) return fail(ctx, MAG_ERR_BAD_ARGS, "mesh has %d tiles, fewer than %d ranks", (int)T, R);
+    // (T < R, not "my range is empty": every rank must take this exit together -- the others would wait in a collective)
+    if (R > 1 && T < R) return fail(ctx, MAG_ERR_BAD_ARGS, "mesh has %d tiles, fewer than %d ranks", (int)T, R);
     // Several ranks, inside mag_run (every rank is here: the phase then ends with two small all-reduces), K assembled from the
     // rows a rank keeps: the tables below are built for the tiles this rank needs only (symbolic.hip, need_tiles).  Any other
     // entry point -- and MAG_TUNE_SHARD_ORDER=0 -- builds them for the whole mesh, as every rank did until round 4.
