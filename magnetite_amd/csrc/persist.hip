@@ -1565,6 +1565,24 @@ __global__ void __launch_bounds__(THREADS) k_cg_persist(const PersistParams P)
     }
 }
 
+// The four-slot edge-block instantiation of ONE GPU -- the kernel of BASELINE config 3 -- is compiled in a translation unit of its
+// own (persist_k4.o: this file again with -DMAG_PERSIST_TU_K4, everything below left out) under the max-ilp scheduler: 5.43
+// against 5.52 us per iteration at 1M triangles in one session, while every other instantiation is FASTER under iterative-ilp
+// (one / two / three node slots 3.48 / 4.08 / 4.65 against 3.53 / 4.16 / 4.83; the overflow instantiation indifferent).  The
+// scheduler is a per-translation-unit option, hence the second object.  Builds without -DMAG_PERSIST_SPLIT_K4 (the stamped
+// build, scripts/build_variant.sh) keep the instantiation in this unit.
+#ifndef MAG_PERSIST_SPLIT_K4
+#define MAG_PERSIST_SPLIT_K4 0
+#endif
+void persist_launch_eb1_k4(const PersistParams &P, int32_t grid, size_t lds, hipStream_t s);
+#ifdef MAG_PERSIST_TU_K4
+void persist_launch_eb1_k4(const PersistParams &P, int32_t grid, size_t lds, hipStream_t s)
+{
+    k_cg_persist<512, false, 512, 1><<<grid, 512, lds, s>>>(P);
+}
+} // namespace magk
+#else
+
 // ========================================= inbox exchange for the STREAMING kernels ===
 // Meshes the chips cannot hold (more than ~0.5M nodes per GPU: BASELINE config 5 on 8 GPUs) run one fused launch per CG
 // iteration, and the ranks must trade [dot partials | q on the interface nodes] between launches.  One RCCL all-reduce
@@ -1777,6 +1795,8 @@ static void persist_launch_t(const PersistParams &P, int32_t B, int32_t grid, si
     } else if (eb_mode == 1) {
         if (B == 256)
             k_cg_persist<256, false, THREADS, 1><<<grid, THREADS, lds, s>>>(P);
+        else if constexpr (MAG_PERSIST_SPLIT_K4 && THREADS == 512)
+            persist_launch_eb1_k4(P, grid, lds, s); // (persist_k4.o: the same instantiation under another scheduler)
         else
             k_cg_persist<512, false, THREADS, 1><<<grid, THREADS, lds, s>>>(P);
     } else if (B == 256)
@@ -2034,3 +2054,4 @@ void mark_published(const int32_t *halo_g, int64_t halo_total, uint8_t *maskP, h
 }
 
 } // namespace magk
+#endif // MAG_PERSIST_TU_K4
