@@ -1,6 +1,8 @@
 #!/bin/bash
 # A variant of the library for A/B runs in one GPU session (scripts/ab_libs.py, MAG_LIB_PATH): persist.hip recompiled with
-# extra -D flags, linked against the objects of the product build.
+# extra -D flags, linked against the objects of the product build.  (The variant is ONE translation unit: it does not define
+# MAG_PERSIST_SPLIT_K4, so the four-slot structured instantiation, which the product compiles separately under max-ilp --
+# persist_k4.o --, is compiled here with the variant's flags and scheduler like every other instantiation.)
 #   bash scripts/build_variant.sh <name> "<-D flags>" [scheduler] [file]     ->  magnetite_amd/ab/libmagnetite_hip_<name>.so
 # file: persist.hip (default) or exact.hip (compiled as the Makefile does: -ffp-contract=off, default scheduler)
 set -e
