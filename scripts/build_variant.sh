@@ -14,7 +14,7 @@ FILE=${4:-persist.hip}
 cd "$ROOT/magnetite_amd/csrc"
 make -s all
 mkdir -p ../ab build
-OBJS="build/primitives.o build/symbolic.o build/exact.o build/cg.o build/persist.o build/api.o build/comm.o"
+OBJS="build/primitives.o build/symbolic.o build/exact.o build/cg.o build/persist.o build/persist_k4.o build/api.o build/comm.o"
 if [ "$FILE" = "exact.hip" ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I../../include -I. -Wall -Wno-unused-result $FLAGS \
         -ffp-contract=off -c exact.hip -o build/exact_$NAME.o
