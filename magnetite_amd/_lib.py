@@ -96,8 +96,9 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64
 
 
 def build(force=False):
-    """hipcc --offload-arch=gfx950 build of the shared library (cross-compiles without a GPU)."""
-    cmd = ["make", "-C", CSRC, "-j6"] + (["-B"] if force else [])
+    """hipcc --offload-arch=gfx950 build of the shared library (cross-compiles without a GPU), and of its diagnostic twin with
+    the in-kernel phase stamps (libmagnetite_hip_stamps.so: scripts/persist_phases*.py load it; the product never does)."""
+    cmd = ["make", "-C", CSRC, "-j6", "all", "stamps"] + (["-B"] if force else [])
     subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
     return SO_PATH
 
